@@ -1,0 +1,186 @@
+"""Pins oracle/torch_ref.py against the UNMODIFIED reference modules.
+
+Runs only where /root/reference exists (the build container).  The reference
+modules are built with their own constructors, loaded with our synthetic
+checkpoints via load_state_dict(strict=True) -- which also proves the
+checkpoint schema -- and executed on CPU.
+"""
+import contextlib
+import io
+
+import pytest
+import torch
+
+from oracle import ref_shim, torch_ref as R
+from text2human_amd import defaults, options, synthetic
+
+pytestmark = [
+    pytest.mark.reference,
+    pytest.mark.skipif(not ref_shim.available(), reason='reference tree absent'),
+]
+
+
+@pytest.fixture(scope='module')
+def ns():
+    return ref_shim.load_reference('cpu')
+
+
+@pytest.fixture(scope='module')
+def opt():
+    return options.dict_to_nonedict(defaults.sample_from_pose())
+
+
+@pytest.fixture(scope='module')
+def sds(opt):
+    return synthetic.make_state_dicts(opt, seed=1234)
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _close(a, b, tol):
+    err = (a - b).abs().max().item()
+    assert err <= tol, f'max abs err {err} > {tol}'
+
+
+def test_decoder_and_res(ns, opt, sds):
+    V = ns.vqgan_arch
+    dec = _quiet(V.Decoder, in_channels=3, resolution=512, z_channels=256, ch=128,
+                 out_ch=3, num_res_blocks=2, attn_resolutions=[32],
+                 ch_mult=[1, 1, 2, 2, 4], dropout=0.0).eval()
+    dec.load_state_dict(sds['decoder'], strict=True)
+    res = _quiet(V.DecoderRes, in_channels=3, resolution=512, z_channels=256, ch=128,
+                 num_res_blocks=2, ch_mult=[1, 1, 2, 4], dropout=0.0).eval()
+    res.load_state_dict(sds['bot_decoder_res'], strict=True)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, 256, 32, 16, generator=g) * 0.05
+    zb = torch.randn(1, 256, 64, 32, generator=g) * 0.05
+    with torch.no_grad():
+        bh = res(zb)
+        _close(R.decoder_res(zb, sds['bot_decoder_res']), bh, 1e-5)
+        _close(R.decoder(z, sds['decoder'], bot_h=bh), dec(z, bot_h=bh.clone()), 1e-5)
+
+
+def test_segm_tokenizer(ns, opt, sds):
+    V = ns.vqgan_arch
+    enc = V.Encoder(ch=64, num_res_blocks=1, attn_resolutions=[16],
+                    ch_mult=[1, 1, 2, 2, 4], in_channels=24, resolution=512,
+                    z_channels=32, double_z=False, dropout=0.0).eval()
+    enc.load_state_dict(sds['segm_encoder'], strict=True)
+    q = V.VectorQuantizer(1024, 32, beta=0.25, sane_index_shape=True).eval()
+    q.load_state_dict(sds['segm_quantizer'], strict=True)
+    qc = torch.nn.Conv2d(32, 32, 1)
+    qc.load_state_dict(sds['segm_quant_conv'], strict=True)
+    batch = synthetic.parsing_batch(2)
+    with torch.no_grad():
+        oh = torch.nn.functional.one_hot(batch['segm'].squeeze(1).long(), 24).permute(0, 3, 1, 2).float()
+        _, _, (_, _, ref_tok) = q(qc(enc(oh)))
+    tok = R.segm_tokens(batch['segm'], sds['segm_encoder'], sds['segm_quant_conv'],
+                        sds['segm_quantizer']['embedding.weight'])
+    assert torch.equal(tok, ref_tok)
+
+
+def test_transformer(ns, opt, sds):
+    T = ns.transformer_arch.TransformerMultiHead(
+        codebook_size=18432, segm_codebook_size=1024, texture_codebook_size=18,
+        bert_n_emb=512, bert_n_layers=24, bert_n_head=8, block_size=512,
+        latent_shape=[32, 16], embd_pdrop=0., resid_pdrop=0., attn_pdrop=0.,
+        num_head=18).eval()
+    T.load_state_dict(sds['sampler'], strict=True)
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 18433, (1, 512), generator=g)
+    seg = torch.randint(0, 1024, (1, 512), generator=g)
+    tex = torch.randint(0, 18, (1, 512), generator=g)
+    with torch.no_grad():
+        ref = T(idx, seg, tex)
+    mine = R.transformer_logits(idx, seg, tex, sds['sampler'])
+    for a, b in zip(mine, ref):
+        _close(a, b, 2e-5)
+
+
+def test_categorical_is_exponential_race():
+    torch.manual_seed(7)
+    logits = torch.randn(64, 1024) * 3
+    torch.manual_seed(99)
+    ref = torch.distributions.Categorical(logits=logits).sample()
+    torch.manual_seed(99)
+    expo = torch.empty(64, 1024).exponential_(1.0)
+    assert torch.equal(R.categorical_argmax(logits, expo), ref)
+
+
+def test_unet_heads_and_pose(ns, opt, sds):
+    U = ns.unet_arch.UNet(in_channels=256).eval()
+    U.load_state_dict(sds['guidance_encoder'], strict=True)
+    H = ns.fcn_arch.MultiHeadFCNHead(in_channels=64, in_index=4, channels=64,
+                                     num_convs=1, concat_input=False,
+                                     dropout_ratio=0.1, num_classes=512,
+                                     align_corners=False, num_head=18).eval()
+    H.load_state_dict(sds['index_decoder'], strict=True)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 256, 32, 16, generator=g) * 0.1
+    with torch.no_grad():
+        ref = H(U(x))
+    mine = R.multihead_fcn(R.unet(x, sds['guidance_encoder'])[4], sds['index_decoder'])
+    for a, b in zip(mine, ref):
+        _close(a, b, 1e-5)
+    # pose front-end
+    E = ns.shape_attr_embedding_arch.ShapeAttrEmbedding(
+        dim=8, out_dim=128, cls_num_list=opt['shape_attr_class_num']).eval()
+    E.load_state_dict(sds['shape_embedder'], strict=True)
+    SU = ns.unet_arch.ShapeUNet(in_channels=1).eval()
+    SU.load_state_dict(sds['shape_encoder'], strict=True)
+    FH = ns.fcn_arch.FCNHead(in_channels=64, in_index=4, channels=64, num_convs=1,
+                             concat_input=False, dropout_ratio=0.1, num_classes=24,
+                             align_corners=False).eval()
+    FH.load_state_dict(sds['shape_decoder'], strict=True)
+    pb = synthetic.pose_batch(1)
+    pose = pb['densepose'][:, :, :128, :64].contiguous()
+    with torch.no_grad():
+        ref_logits = FH(SU(pose, E(pb['shape_attr'])))
+    segm, logits = R.parsing_from_pose(pose, pb['shape_attr'], sds['shape_embedder'],
+                                       sds['shape_encoder'], sds['shape_decoder'],
+                                       opt['shape_attr_class_num'])
+    _close(logits, ref_logits, 1e-5)
+    assert torch.equal(segm, ref_logits.argmax(1, keepdim=True))
+
+
+@pytest.fixture(scope='module')
+def ref_model(ns, opt, tmp_path_factory):
+    d = tmp_path_factory.mktemp('ckpt')
+    o = synthetic.write_checkpoints(opt, str(d), seed=1234)
+    o['model_type'] = 'SampleFromParsingModel'
+    return _quiet(ns.sample_model.SampleFromParsingModel, o), o
+
+
+def test_end_to_end_sample_from_parsing(ns, opt, sds, ref_model):
+    model, o = ref_model
+    model.sample_steps = 5
+    batch = synthetic.parsing_batch(2)
+    ref_shim.saved_images.clear()
+    ns.util.set_random_seed(2021)
+    model.feed_data(batch)
+    with torch.no_grad():
+        ref_top = model.sample_fn(temp=1, sample_steps=5)
+    ns.util.set_random_seed(2021)
+    with torch.no_grad():
+        model.sample_and_refine('/nonexistent', batch['img_name'])
+    ref_imgs = torch.cat([t for t, _ in ref_shim.saved_images], 0)
+
+    torch.manual_seed(2021)
+    img, inter = R.sample_from_parsing(batch['segm'], batch['texture_mask'], sds,
+                                       sample_steps=5, noise=R.TorchNoise('cpu'))
+    assert torch.equal(inter['segm_tokens'], model.segm_tokens)
+    for a, b in zip(inter['top_indices'], ref_top):
+        assert torch.equal(a, b)
+    _close(img, ref_imgs, 1e-5)
+
+
+def test_texture_map_rule(ns):
+    g = torch.Generator().manual_seed(3)
+    segm = torch.randint(0, 24, (3, 1, 8, 8), generator=g)
+    up, lo, ou = torch.tensor([3, 17, 0]), torch.tensor([17, 5, 2]), torch.tensor([1, 1, 17])
+    m = R.texture_map(segm, up, lo, ou)
+    m2 = synthetic.texture_mask_from_segm(segm.float(), up, lo, ou)
+    assert torch.equal(m, m2)
