@@ -1,0 +1,192 @@
+/*
+ * libt2h_hip.so -- C ABI of the MI355X (gfx950) kernels behind the Text2Human
+ * sampling hot path (sample_from_parsing / sample_from_pose).
+ *
+ * The reference (yumingj/Text2Human) is pure PyTorch and has NO FFI / operator
+ * plug-in interface; every entry point below replaces a group
+ * of eager PyTorch op call sites, cited as reference file:line.  The host side
+ * (text2human_amd python package) binds these with ctypes; INTEGRATION.md shows the stub
+ * a reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless named host_*;
+ *  - `stream` is a hipStream_t passed as void*; all calls are asynchronous on
+ *    it, never synchronise and never allocate;
+ *  - activations of the conv stacks are NHWC fp32 ("pixel rows": [B*H*W, C]),
+ *    transformer activations are [B*T, C] fp32, indices are int64 like the
+ *    reference's LongTensors, masks are uint8;
+ *  - every entry returns 0 on success or a negative t2h_status; the message
+ *    for the calling thread is available from t2h_last_error().
+ */
+#ifndef T2H_HIP_H
+#define T2H_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum t2h_status {
+  T2H_OK = 0,
+  T2H_ERR_INVALID = -1,   /* bad argument (shape / alignment / NULL) */
+  T2H_ERR_LAUNCH = -2,    /* hipLaunch / runtime error */
+  T2H_ERR_UNSUPPORTED = -3
+};
+
+int t2h_version(void);
+const char* t2h_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM ---
+ * C[M,N] = epi( alpha * A'[M,K] * B[N,K]^T + bias[N] ) + residual[M,N]
+ * on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 fma chains).
+ *
+ * A' is either the plain row-major matrix A (a_mode 0) or the implicit im2col
+ * view of an NHWC image (a_mode 1: 3x3 taps, K = 9*Cin ordered [tap][cin]),
+ * optionally preceded by a per-(image, channel) affine + activation prologue
+ * (GroupNorm apply + swish fused into the operand load).
+ *
+ * Replaces: every nn.Linear of the sampler (models/archs/transformer_arch.py:
+ * 41-49,70,84-89,271), 1x1 convs (vqgan_arch.py:590-595,627-634, post-quant
+ * convs models/sample_model.py:230,240), 3x3 convs incl. nearest-x2 Upsample
+ * and asym-padded stride-2 Downsample (vqgan_arch.py:526-551,573-580,954,997),
+ * torch.bmm of AttnBlock (vqgan_arch.py:645-656), mmcv ConvModule conv+BN+ReLU
+ * (models/archs/unet_arch.py:160-171, fcn_arch.py:297-305; BN folded by the
+ * loader).
+ */
+typedef struct t2h_gemm_args {
+  const float* A;         /* plain: [M,K] lda; conv: NHWC input [Bimg,Hin,Win,>=Cin], pixel stride lda */
+  const float* B;         /* weights [N,K] row-major (ldb) or, b_trans=1, [K,N] (ldb) */
+  float* C;               /* [M,N] ldc */
+  const float* bias;      /* [N] or NULL */
+  const float* residual;  /* [M,N] ldr or NULL; added after the activation, or before it if res_pre */
+  const float* pro_scale; /* [n_img, pro_ld] or NULL: a' = act(a*scale + shift) */
+  const float* pro_shift;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc, ldr;
+  int32_t a_mode;         /* 0 plain, 1 conv3x3 */
+  int32_t b_trans;        /* 0 / 1 (plain A, no prologue only) */
+  int32_t pro_act;        /* 0 none, 1 swish x*sigmoid(x) */
+  int32_t pro_rows;       /* plain mode: rows per image (H*W) for the prologue table */
+  int32_t pro_ld;         /* channels per table row */
+  int32_t epi_act;        /* 0 none, 1 GELU(erf), 2 ReLU */
+  int32_t res_pre;        /* 1: residual is added BEFORE the activation (per-pixel bias map) */
+  float alpha;
+  int32_t Hin, Win, Cin;  /* conv: input image geometry (pre-upsample) */
+  int32_t Hout, Wout;     /* conv: output geometry; M = n_img*Hout*Wout */
+  int32_t stride, pad;    /* (1,1) same conv; (2,0) asym-padded downsample */
+  int32_t ups;            /* 1: input is nearest-upsampled x2 on the fly */
+  int32_t batch;          /* >=1: independent problems (blockIdx.z) */
+  int64_t strideA, strideB, strideC; /* element strides between problems */
+} t2h_gemm_args;
+
+int t2h_gemm_f32(const t2h_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------ normalisation ------
+ * LayerNorm over the last dim (eps 1e-5): transformer_arch.py:80-81,93-95,231,270 */
+int t2h_layernorm_f32(const float* x, const float* gamma, const float* beta,
+                      float* y, int32_t rows, int32_t C, float eps, void* stream);
+
+/* GroupNorm(32 groups, eps 1e-6) statistics of an NHWC tensor turned into the
+ * per-(image, channel) scale/shift tables consumed by the GEMM prologue
+ * (vqgan_arch.py:515-517).  workspace: n_img*chunks*2*C doubles. */
+int64_t t2h_groupnorm_workspace_bytes(int32_t n_img, int32_t HW, int32_t C);
+int t2h_groupnorm_tables_f32(const float* x, int32_t ldx, const float* gamma,
+                             const float* beta, float* scale, float* shift,
+                             int32_t n_img, int32_t HW, int32_t C, int32_t groups,
+                             float eps, void* workspace, void* stream);
+
+/* in-place row softmax of [rows, n] (AttnBlock, vqgan_arch.py:647) */
+int t2h_softmax_rows_f32(float* x, int32_t rows, int32_t n, int32_t ld, void* stream);
+
+/* ------------------------------------------------------ sampler ------------
+ * x[B*T, C] = tok_emb[idx] + pos_emb[t] + segm_emb[segm] + texture_emb[tex]
+ * (transformer_arch.py:251-266) */
+int t2h_embed_sum4_f32(const int64_t* idx, const int64_t* segm, const int64_t* tex,
+                       const float* tok_emb, const float* pos_emb,
+                       const float* segm_emb, const float* tex_emb, float* x,
+                       int32_t B, int32_t T, int32_t C, void* stream);
+
+/* non-causal multi-head attention over a packed [B*T, 3*C] q|k|v buffer
+ * (CausalSelfAttention.forward with causal=False, transformer_arch.py:37-67).
+ * T % 128 == 0, head_dim == 64. */
+int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int32_t T,
+                          int32_t n_head, void* stream);
+
+/* one step of the absorbing-diffusion unmasking schedule
+ * (models/sample_model.py:286-292,301-302): changes = rand < 1/t & ~unmasked;
+ * unmasked |= changes; head_count[h] += #changed tokens of texture h. */
+int t2h_unmask_step(const float* rand, int32_t t, uint8_t* unmasked, uint8_t* changes,
+                    const int64_t* tex, int32_t* head_count, int32_t n, void* stream);
+
+/* texture-routed categorical sampling of the changed tokens of ONE head
+ * (models/sample_model.py:304-317 + ln_f and head_list[h] of
+ * transformer_arch.py:270-271): for rows with changes && tex==head:
+ *   logits = W_head * LN_f(hidden[row]); x0 = argmax(softmax(logits/temp)/expo[row]);
+ *   x_t[row] = x0 + 1024*head; out_idx[row] = x0.
+ * expo is the reference's full [n, n_class] Exp(1) draw for this head. */
+int t2h_sample_head(const float* hidden, const float* lnf_gamma, const float* lnf_beta,
+                    const float* w_head, const float* expo, const uint8_t* changes,
+                    const int64_t* tex, int32_t head, float temp, int64_t* x_t,
+                    int64_t* out_idx, int32_t n, int32_t C, int32_t n_class,
+                    void* stream);
+
+/* ------------------------------------------------------ quantizers ---------
+ * VectorQuantizer.forward distance+argmin, vqgan_arch.py:88-92 (first min wins) */
+int t2h_vq_l2_argmin_f32(const float* z, const float* codebook, int64_t* idx,
+                         int32_t n, int32_t n_e, int32_t d, void* stream);
+
+/* VectorQuantizerTexture.get_codebook_entry, vqgan_arch.py:289-309:
+ * out[row, :] = books[tex[row]][idx[tex[row]][row]]  (idx_lists: [18, n]) */
+int t2h_codebook_gather_tex_f32(const int64_t* idx_lists, const int64_t* tex,
+                                const float* books, float* out, int32_t n,
+                                int32_t n_books, int32_t n_e, int32_t e_dim,
+                                void* stream);
+
+/* VectorQuantizerSpatialTextureAware.get_codebook_entry incl. F.fold(k=2,s=2),
+ * vqgan_arch.py:463-486: NHWC out [B, 2h, 2w, C] from [C*4]-entries ([c,kh,kw]) */
+int t2h_codebook_gather_fold_f32(const int64_t* idx_lists, const int64_t* tex,
+                                 const float* books, float* out, int32_t B,
+                                 int32_t h, int32_t w, int32_t n_books, int32_t n_e,
+                                 int32_t C, void* stream);
+
+/* texture-routed 1x1 head + argmax of bot_index_prediction
+ * (fcn_arch.py:338-346, models/sample_model.py:200-207):
+ * out_lists[h][row] = argmax_k(W[h][k,:]*feat[row, h*Cf:(h+1)*Cf] + b[h][k]) if tex[row]==h else -1 */
+int t2h_routed_head_argmax(const float* feat, int32_t ldf, const float* w,
+                           const float* b, const int64_t* tex, int64_t* out_lists,
+                           int32_t n, int32_t n_heads, int32_t Cf, int32_t n_class,
+                           void* stream);
+
+/* ------------------------------------------------------ layout / misc ------ */
+/* F.one_hot(segm).permute(0,3,1,2) (models/sample_model.py:332-335) as NHWC
+ * with the channel dim zero-padded to Cpad */
+int t2h_onehot_nhwc_f32(const float* segm, float* out, int64_t n_pix, int32_t n_cls,
+                        int32_t Cpad, void* stream);
+int t2h_nchw_to_nhwc_f32(const float* x, float* y, int32_t B, int32_t C, int32_t HW,
+                         int32_t ldy, void* stream);
+int t2h_nhwc_to_nchw_f32(const float* x, int32_t ldx, float* y, int32_t B, int32_t C,
+                         int32_t HW, void* stream);
+/* nn.MaxPool2d(2) on NHWC (unet_arch.py:432) */
+int t2h_maxpool2_nhwc_f32(const float* x, int32_t ldx, float* y, int32_t B, int32_t H,
+                          int32_t W, int32_t C, void* stream);
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) on NHWC
+ * (unet_arch.py:285-286) */
+int t2h_bilinear_up2_nhwc_f32(const float* x, float* y, int32_t B, int32_t H, int32_t W,
+                              int32_t C, void* stream);
+/* argmax over the channel dim of NHWC rows -> int64 (sample_model.py:436) */
+int t2h_argmax_rows_f32(const float* x, int32_t ld, int64_t* out, int64_t rows,
+                        int32_t n, void* stream);
+/* ((dec+1)/2).clamp(0,1) NHWC[.,3] -> NCHW f32 image and (optional) HWC uint8
+ * mul(255).add(0.5).clamp(0,255) (models/sample_model.py:245-254) */
+int t2h_image_epilogue(const float* dec, int32_t ldd, float* img_nchw, uint8_t* img_u8,
+                       int32_t B, int32_t HW, void* stream);
+/* generate_texture_map rule (models/sample_model.py:443-467) */
+int t2h_texture_map(const int64_t* segm, const int64_t* upper, const int64_t* lower,
+                    const int64_t* outer, float* mask, int32_t B, int32_t HW,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2H_HIP_H */

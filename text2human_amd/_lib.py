@@ -1,0 +1,96 @@
+"""ctypes binding of libt2h_hip.so (include/t2h_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol
+cannot be resolved, importing the ops fails loudly (the oracle under oracle/ is
+test infrastructure and is never used here).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libt2h_hip.so')
+
+c_f32p = ctypes.c_void_p
+c_i64p = ctypes.c_void_p
+c_u8p = ctypes.c_void_p
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_vp = ctypes.c_void_p
+
+
+class GemmArgs(ctypes.Structure):
+    """struct t2h_gemm_args (include/t2h_hip.h)."""
+    _fields_ = [
+        ('A', c_vp), ('B', c_vp), ('C', c_vp), ('bias', c_vp), ('residual', c_vp),
+        ('pro_scale', c_vp), ('pro_shift', c_vp),
+        ('M', c_i32), ('N', c_i32), ('K', c_i32),
+        ('lda', c_i32), ('ldb', c_i32), ('ldc', c_i32), ('ldr', c_i32),
+        ('a_mode', c_i32), ('b_trans', c_i32), ('pro_act', c_i32),
+        ('pro_rows', c_i32), ('pro_ld', c_i32), ('epi_act', c_i32), ('res_pre', c_i32),
+        ('alpha', c_f32),
+        ('Hin', c_i32), ('Win', c_i32), ('Cin', c_i32), ('Hout', c_i32), ('Wout', c_i32),
+        ('stride', c_i32), ('pad', c_i32), ('ups', c_i32), ('batch', c_i32),
+        ('strideA', c_i64), ('strideB', c_i64), ('strideC', c_i64),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/t2h_hip.h
+SIGNATURES = {
+    't2h_version': (ctypes.c_int, []),
+    't2h_last_error': (ctypes.c_char_p, []),
+    't2h_gemm_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp]),
+    't2h_layernorm_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
+    't2h_groupnorm_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32]),
+    't2h_groupnorm_tables_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                                c_i32, c_i32, c_f32, c_vp, c_vp]),
+    't2h_softmax_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp]),
+    't2h_embed_sum4_f32': (ctypes.c_int, [c_vp] * 8 + [c_i32, c_i32, c_i32, c_vp]),
+    't2h_mha_noncausal_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    't2h_unmask_step': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    't2h_sample_head': (ctypes.c_int, [c_vp] * 7 + [c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    't2h_vq_l2_argmin_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    't2h_codebook_gather_tex_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    't2h_codebook_gather_fold_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                                    c_i32, c_i32, c_vp]),
+    't2h_routed_head_argmax': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                              c_i32, c_vp]),
+    't2h_onehot_nhwc_f32': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    't2h_nchw_to_nhwc_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    't2h_nhwc_to_nchw_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    't2h_maxpool2_nhwc_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    't2h_bilinear_up2_nhwc_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    't2h_argmax_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i32, c_vp]),
+    't2h_image_epilogue': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    't2h_texture_map': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+}
+
+_lib = None
+
+
+class T2HError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libt2h_hip.so and resolves every declared symbol (fails loudly)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise T2HError(
+            f'{LIB_PATH} not found: build it with `python -m text2human_amd.build` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=''):
+    if status != 0:
+        msg = load().t2h_last_error()
+        raise T2HError(f'{what} failed ({status}): {msg.decode() if msg else "?"}')

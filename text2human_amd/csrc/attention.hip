@@ -1,0 +1,173 @@
+// Non-causal multi-head self-attention of the index sampler, fp32 MFMA, flash
+// style (no TxT matrix in HBM).  Replaces CausalSelfAttention.forward with
+// causal=False (models/archs/transformer_arch.py:52-67): softmax(q k^T/sqrt(64)) v.
+//
+// Workgroup = 4 waves = 128 query rows of one (batch, head); wave w owns 32
+// queries.  Keys/values stream through LDS in tiles of 64 keys.
+//
+// Both matmuls are issued in TRANSPOSED form so that everything indexed by the
+// query stays lane-local (lane&31 = query, lane>>5 = k-half of the MFMA):
+//   S^T[key][q]  = sum_d K[key][d] * Q[q][d]      A = K tile (LDS), B = Q (regs)
+//   O^T[d][q]   += sum_key V[key][d] * P[q][key]   A = V^T (LDS),  B = P (regs)
+// The C/D layout of v_mfma_f32_32x32x2_f32 (col = lane&31, row = (r&3) +
+// 8*(r>>2) + 4*(lane>>5)) puts, for S^T, query = lane&31 and 16 keys in the 16
+// accumulator registers of each lane; the second MFMA wants B[k][j] from lane
+// (j = query, k-half h) -- exactly those registers if MFMA step s contracts the
+// key pair {(s&3)+8(s>>2)+4h, h=0,1}.  So P never leaves registers, the online
+// softmax statistics (running max m, running sum l) are per-lane scalars, and
+// rescaling the O^T accumulator is a plain per-lane multiply.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;       // head dim
+constexpr int QB = 128;      // queries per workgroup
+constexpr int KT = 64;       // keys per LDS tile
+constexpr int K_LD = 68;     // K tile row stride (17 x 16B slots, odd -> conflict-free b128)
+constexpr int V_LD = 64;
+constexpr int O_LD = 68;
+
+__global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
+                                                  float* __restrict__ y, int T, int C) {
+  constexpr int SMEM_KV = KT * K_LD + KT * V_LD;
+  constexpr int SMEM_O = 4 * 32 * O_LD;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_KV > SMEM_O ? SMEM_KV : SMEM_O];
+  float* const Ks = smem;
+  float* const Vs = smem + KT * K_LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB + wave * 32;
+  const int ld = 3 * C;
+  const float* base = qkv + (int64_t)b * T * ld + head * HD;
+
+  // Q fragment: lane (q = l31, h) holds Q[q][32h + s] * 1/8, s = 0..31
+  float qf[32];
+  {
+    const float* qp = base + (int64_t)(q0 + l31) * ld + 32 * hh;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + 4 * s4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qf[4 * s4 + e] = v[e] * 0.125f;
+    }
+  }
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: K/V tile = 64 keys x 64 floats = 1024 float4 each -> 4 + 4 per thread
+  const int s_col4 = tid & 15, s_row0 = tid >> 4;  // 16 float4 per key row, 16 rows per pass
+  f32x4 kreg[4], vreg[4];
+  auto load_kv = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = kt * KT + s_row0 + 16 * i;
+      const float* p = base + (int64_t)key * ld + s_col4 * 4;
+      kreg[i] = *reinterpret_cast<const f32x4*>(p + C);
+      vreg[i] = *reinterpret_cast<const f32x4*>(p + 2 * C);
+    }
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = s_row0 + 16 * i;
+      *reinterpret_cast<f32x4*>(Ks + r * K_LD + s_col4 * 4) = kreg[i];
+      *reinterpret_cast<f32x4*>(Vs + r * V_LD + s_col4 * 4) = vreg[i];
+    }
+  };
+
+  const int nkt = T / KT;
+  load_kv(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+    store_kv();
+    __syncthreads();
+    if (kt + 1 < nkt) load_kv(kt + 1);
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // two 32-key sub-tiles
+      // ---- S^T = K Q^T
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      const float* kp = Ks + (ks * 32 + l31) * K_LD + 32 * hh;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[4 * j + e], st, 0, 0, 0);
+      }
+      // ---- online softmax over this lane's 16 keys + partner half's 16 keys
+      float mx = st[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = expf(m_run - m_new);  // first tile: exp(-inf) = 0
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = expf(st[r] - m_new);
+        psum += st[r];
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[dt][r] *= alpha;
+      // ---- O^T += V^T P^T ; step s contracts keys {(s&3)+8(s>>2)+4h}
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int key = ks * 32 + (s & 3) + 8 * (s >> 2) + 4 * hh;
+        const float* vp = Vs + key * V_LD + l31;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * dt], st[s], o_acc[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise, transpose through LDS, coalesced row stores
+  __syncthreads();
+  float* Os = smem + wave * 32 * O_LD;
+  const float inv_l = 1.0f / l_run;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      Os[l31 * O_LD + d] = o_acc[dt][r] * inv_l;
+    }
+  __syncthreads();
+  float* yb = y + ((int64_t)b * T + q0) * C + head * HD;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+    *reinterpret_cast<f32x4*>(yb + (int64_t)row * C + c4) =
+        *reinterpret_cast<const f32x4*>(Os + row * O_LD + c4);
+  }
+}
+
+}  // namespace
+
+extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int32_t T,
+                                     int32_t n_head, void* stream) {
+  T2H_REQUIRE(qkv && y, "t2h_mha_noncausal_f32: NULL pointer");
+  T2H_REQUIRE(B > 0 && n_head > 0, "t2h_mha_noncausal_f32: empty problem");
+  T2H_REQUIRE(T > 0 && T % QB == 0, "t2h_mha_noncausal_f32: T=%d must be a multiple of %d", T, QB);
+  T2H_REQUIRE(t2h_aligned16(qkv) && t2h_aligned16(y), "t2h_mha_noncausal_f32: 16-byte alignment");
+  const int C = n_head * HD;
+  dim3 grid(T / QB, n_head, B), block(256);
+  hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv, y, T, C);
+  T2H_CHECK_LAUNCH("t2h_mha_noncausal_f32");
+  return T2H_OK;
+}

@@ -1,0 +1,232 @@
+// LayerNorm, GroupNorm statistics -> prologue tables, row softmax.
+#include "common.h"
+
+namespace {
+
+// One wave per row; each lane keeps its C/64 values in registers, two passes
+// (mean, then centred variance) like torch's rowwise moments.
+template <int VPL>  // float4 vectors per lane: C = 256 * VPL
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        float* __restrict__ y, int rows,
+                                                        float eps) {
+  constexpr int C = 256 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * C;
+  f32x4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      q = fmaf(d, d, q);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+  float* yr = y + (int64_t)row * C;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 256 + lane * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + i * 256 + lane * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+    *reinterpret_cast<f32x4*>(yr + i * 256 + lane * 4) = o;
+  }
+}
+
+// ---- GroupNorm statistics.  Grid (chunks, n_img).  Thread t owns the channel
+// quad (t % (C/4)) and walks pixels with stride 256/(C/4); per-channel partial
+// sums in fp64 (fp64 VALU is cheap on CDNA and removes the E[x^2]-E[x]^2
+// cancellation worry), block-reduced per channel, written as partials.
+constexpr int GN_PIX_PER_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int ldx,
+                                                         int HW, int C, int chunks,
+                                                         double* __restrict__ part) {
+  __shared__ double red[2][256][4];
+  const int tid = threadIdx.x;
+  const int q_per_pix = C >> 2;           // float4 per pixel
+  const int pix_stride = 256 / q_per_pix;  // pixels covered per pass
+  const int cq = tid % q_per_pix, p_lane = tid / q_per_pix;
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int p_begin = chunk * GN_PIX_PER_BLOCK;
+  const int p_end = min(HW, p_begin + GN_PIX_PER_BLOCK);
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  const float* xb = x + (int64_t)img * HW * ldx + cq * 4;
+  for (int p = p_begin + p_lane; p < p_end; p += pix_stride) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)p * ldx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double d = (double)v[e];
+      s[e] += d;
+      ss[e] = fma(d, d, ss[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][tid][e] = s[e];
+    red[1][tid][e] = ss[e];
+  }
+  __syncthreads();
+  if (tid < q_per_pix) {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    for (int r = 0; r < pix_stride; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] += red[0][r * q_per_pix + tid][e];
+        b[e] += red[1][r * q_per_pix + tid][e];
+      }
+    double* out = part + (((int64_t)img * chunks + chunk) * 2) * C + tid * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      out[e] = a[e];
+      out[C + e] = b[e];
+    }
+  }
+}
+
+// Grid n_img, block = C threads (<= 1024): thread c reduces its channel over the
+// chunks, groups are combined through LDS, then scale/shift tables are emitted.
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int chunks, int HW, int C,
+                                   int groups, float eps, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+  __shared__ double cs[1024], css[1024];
+  __shared__ float g_mean[64], g_rstd[64];
+  const int c = threadIdx.x, img = blockIdx.x;
+  double s = 0, ss = 0;
+  for (int k = 0; k < chunks; ++k) {
+    const double* p = part + (((int64_t)img * chunks + k) * 2) * C;
+    s += p[c];
+    ss += p[C + c];
+  }
+  cs[c] = s;
+  css[c] = ss;
+  __syncthreads();
+  const int cpg = C / groups;
+  if (c < groups) {
+    double a = 0, b = 0;
+    for (int i = 0; i < cpg; ++i) {
+      a += cs[c * cpg + i];
+      b += css[c * cpg + i];
+    }
+    const double n = (double)HW * cpg;
+    const double mean = a / n;
+    double var = b / n - mean * mean;
+    if (var < 0) var = 0;
+    g_mean[c] = (float)mean;
+    g_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int g = c / cpg;
+  const float sc = g_rstd[g] * gamma[c];
+  scale[(int64_t)img * C + c] = sc;
+  shift[(int64_t)img * C + c] = fmaf(-g_mean[g], sc, beta[c]);
+}
+
+// In-place softmax of each row; one wave per row, the row (n <= 64*MAXV) stays
+// in registers between the max, exp-sum and normalise passes.
+template <int MAXV>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int rows, int n,
+                                                           int ld) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* xr = x + (int64_t)row * ld;
+  float v[MAXV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < n ? xr[c] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    v[i] = expf(v[i] - mx);
+    s += v[i];
+  }
+  const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < n) xr[c] = v[i] * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int t2h_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                 int32_t rows, int32_t C, float eps, void* stream) {
+  T2H_REQUIRE(x && gamma && beta && y, "t2h_layernorm_f32: NULL pointer");
+  T2H_REQUIRE(rows > 0, "t2h_layernorm_f32: rows=%d", rows);
+  T2H_REQUIRE(t2h_aligned16(x) && t2h_aligned16(y) && t2h_aligned16(gamma) && t2h_aligned16(beta),
+              "t2h_layernorm_f32: 16-byte alignment");
+  dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (C == 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+  else if (C == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+  else if (C == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+  else {
+    t2h_set_error("t2h_layernorm_f32: C=%d unsupported (256/512/1024)", C);
+    return T2H_ERR_UNSUPPORTED;
+  }
+  T2H_CHECK_LAUNCH("t2h_layernorm_f32");
+  return T2H_OK;
+}
+
+static int gn_chunks(int HW) { return (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK; }
+
+extern "C" int64_t t2h_groupnorm_workspace_bytes(int32_t n_img, int32_t HW, int32_t C) {
+  return (int64_t)n_img * gn_chunks(HW) * 2 * C * (int64_t)sizeof(double);
+}
+
+extern "C" int t2h_groupnorm_tables_f32(const float* x, int32_t ldx, const float* gamma,
+                                        const float* beta, float* scale, float* shift,
+                                        int32_t n_img, int32_t HW, int32_t C, int32_t groups,
+                                        float eps, void* workspace, void* stream) {
+  T2H_REQUIRE(x && gamma && beta && scale && shift && workspace, "t2h_groupnorm_tables_f32: NULL pointer");
+  T2H_REQUIRE(n_img > 0 && HW > 0, "t2h_groupnorm_tables_f32: empty problem");
+  T2H_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && C / 4 <= 256,
+              "t2h_groupnorm_tables_f32: C=%d unsupported", C);
+  T2H_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "t2h_groupnorm_tables_f32: groups=%d", groups);
+  T2H_REQUIRE(ldx % 4 == 0 && t2h_aligned16(x), "t2h_groupnorm_tables_f32: alignment");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int chunks = gn_chunks(HW);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n_img), dim3(256), 0, s, x, ldx, HW, C, chunks,
+                     static_cast<double*>(workspace));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img), dim3(C), 0, s,
+                     static_cast<const double*>(workspace), chunks, HW, C, groups, eps, gamma, beta,
+                     scale, shift);
+  T2H_CHECK_LAUNCH("t2h_groupnorm_tables_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_softmax_rows_f32(float* x, int32_t rows, int32_t n, int32_t ld, void* stream) {
+  T2H_REQUIRE(x, "t2h_softmax_rows_f32: NULL pointer");
+  T2H_REQUIRE(rows > 0 && n > 0 && ld >= n, "t2h_softmax_rows_f32: bad shape");
+  dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n <= 512) hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, s, x, rows, n, ld);
+  else if (n <= 2048) hipLaunchKernelGGL(softmax_rows_kernel<32>, grid, block, 0, s, x, rows, n, ld);
+  else if (n <= 8192) hipLaunchKernelGGL(softmax_rows_kernel<128>, grid, block, 0, s, x, rows, n, ld);
+  else {
+    t2h_set_error("t2h_softmax_rows_f32: n=%d > 8192 unsupported", n);
+    return T2H_ERR_UNSUPPORTED;
+  }
+  T2H_CHECK_LAUNCH("t2h_softmax_rows_f32");
+  return T2H_OK;
+}

@@ -1,0 +1,187 @@
+// Index-sampler glue kernels: 4-way embedding sum, the unmasking schedule step
+// and the texture-routed categorical sampling tail.
+#include "common.h"
+
+namespace {
+
+// x[row] = ((tok_emb[idx] + pos_emb[t]) + segm_emb[segm]) + texture_emb[tex]
+// -- same association order as models/archs/transformer_arch.py:266.
+__global__ void embed_sum4_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ segm,
+                                  const int64_t* __restrict__ tex, const float* __restrict__ tok_emb,
+                                  const float* __restrict__ pos_emb, const float* __restrict__ segm_emb,
+                                  const float* __restrict__ tex_emb, float* __restrict__ x, int T,
+                                  int C) {
+  const int row = blockIdx.x;
+  const int t = row % T;
+  const float* a = tok_emb + idx[row] * C;
+  const float* b = pos_emb + (int64_t)t * C;
+  const float* c = segm_emb + segm[row] * C;
+  const float* d = tex_emb + tex[row] * C;
+  float* o = x + (int64_t)row * C;
+  for (int i = threadIdx.x * 4; i < C; i += blockDim.x * 4) {
+    const f32x4 va = *reinterpret_cast<const f32x4*>(a + i);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(b + i);
+    const f32x4 vc = *reinterpret_cast<const f32x4*>(c + i);
+    const f32x4 vd = *reinterpret_cast<const f32x4*>(d + i);
+    *reinterpret_cast<f32x4*>(o + i) = ((va + vb) + vc) + vd;
+  }
+}
+
+// changes = rand < 1/t ; changes &= ~unmasked ; unmasked |= changes
+// (models/sample_model.py:286-292).  `1 / t.float()` is an fp32 reciprocal.
+__global__ void unmask_step_kernel(const float* __restrict__ rnd, float thresh,
+                                   uint8_t* __restrict__ unmasked, uint8_t* __restrict__ changes,
+                                   const int64_t* __restrict__ tex, int* __restrict__ head_count,
+                                   int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool um = unmasked[i] != 0;
+  const bool ch = (rnd[i] < thresh) && !um;
+  changes[i] = ch ? 1 : 0;
+  if (ch) {
+    unmasked[i] = 1;
+    atomicAdd(head_count + (int)tex[i], 1);
+  }
+}
+
+// One workgroup per token row; rows that are not (changed && of this head's
+// texture) exit at once.  LN_f -> 512->n_class head (wave-cooperative dot
+// products, coalesced weight rows) -> exponential-race argmax.
+template <int C>
+__global__ __launch_bounds__(256) void sample_head_kernel(
+    const float* __restrict__ hidden, const float* __restrict__ g, const float* __restrict__ bta,
+    const float* __restrict__ w, const float* __restrict__ expo, const uint8_t* __restrict__ changes,
+    const int64_t* __restrict__ tex, int head, float inv_temp, int64_t* __restrict__ x_t,
+    int64_t* __restrict__ out_idx, int n_class) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // n_class logits + 2*4 reduce slots
+  const int row = blockIdx.x;
+  if (!changes[row] || (int)tex[row] != head) return;
+  constexpr int VPL = C / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = hidden + (int64_t)row * C;
+  f32x4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      q = fmaf(d, d, q);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i * 256 + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + i * 256 + lane * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+  }
+  // logits: wave `wave` handles classes wave, wave+4, ...
+  for (int j = wave; j < n_class; j += 4) {
+    const float* wr = w + (int64_t)j * C;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + i * 256 + lane * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = fmaf(ww[e], v[i][e], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) lds[j] = acc * inv_temp;
+  }
+  __syncthreads();
+  float* red = lds + n_class;
+  float mx = -INFINITY;
+  for (int j = tid; j < n_class; j += 256) mx = fmaxf(mx, lds[j]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  // argmax_j exp(l_j - max) / q_j  (first index wins ties)
+  const float* er = expo + (int64_t)row * n_class;
+  float best = -1.f;
+  int best_j = 0x7fffffff;
+  for (int j = tid; j < n_class; j += 256) {
+    const float sc = expf(lds[j] - mx) / er[j];
+    if (sc > best) {
+      best = sc;
+      best_j = j;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oj = __shfl_xor(best_j, o, 64);
+    if (ob > best || (ob == best && oj < best_j)) {
+      best = ob;
+      best_j = oj;
+    }
+  }
+  __syncthreads();
+  int* redj = reinterpret_cast<int*>(red + 4);
+  if (lane == 0) {
+    red[wave] = best;
+    redj[wave] = best_j;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (red[k] > best || (red[k] == best && redj[k] < best_j)) {
+        best = red[k];
+        best_j = redj[k];
+      }
+    x_t[row] = (int64_t)best_j + (int64_t)n_class * head;
+    out_idx[row] = best_j;
+  }
+}
+
+}  // namespace
+
+extern "C" int t2h_embed_sum4_f32(const int64_t* idx, const int64_t* segm, const int64_t* tex,
+                                  const float* tok_emb, const float* pos_emb, const float* segm_emb,
+                                  const float* tex_emb, float* x, int32_t B, int32_t T, int32_t C,
+                                  void* stream) {
+  T2H_REQUIRE(idx && segm && tex && tok_emb && pos_emb && segm_emb && tex_emb && x,
+              "t2h_embed_sum4_f32: NULL pointer");
+  T2H_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0, "t2h_embed_sum4_f32: bad shape");
+  hipLaunchKernelGGL(embed_sum4_kernel, dim3(B * T), dim3(128), 0, static_cast<hipStream_t>(stream),
+                     idx, segm, tex, tok_emb, pos_emb, segm_emb, tex_emb, x, T, C);
+  T2H_CHECK_LAUNCH("t2h_embed_sum4_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_unmask_step(const float* rnd, int32_t t, uint8_t* unmasked, uint8_t* changes,
+                               const int64_t* tex, int32_t* head_count, int32_t n, void* stream) {
+  T2H_REQUIRE(rnd && unmasked && changes && tex && head_count, "t2h_unmask_step: NULL pointer");
+  T2H_REQUIRE(t >= 1 && n > 0, "t2h_unmask_step: t=%d n=%d", t, n);
+  const float thresh = 1.0f / (float)t;
+  hipLaunchKernelGGL(unmask_step_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), rnd, thresh, unmasked, changes, tex,
+                     head_count, n);
+  T2H_CHECK_LAUNCH("t2h_unmask_step");
+  return T2H_OK;
+}
+
+extern "C" int t2h_sample_head(const float* hidden, const float* lnf_gamma, const float* lnf_beta,
+                               const float* w_head, const float* expo, const uint8_t* changes,
+                               const int64_t* tex, int32_t head, float temp, int64_t* x_t,
+                               int64_t* out_idx, int32_t n, int32_t C, int32_t n_class,
+                               void* stream) {
+  T2H_REQUIRE(hidden && lnf_gamma && lnf_beta && w_head && expo && changes && tex && x_t && out_idx,
+              "t2h_sample_head: NULL pointer");
+  T2H_REQUIRE(n > 0 && n_class > 0 && temp > 0.f, "t2h_sample_head: bad arguments");
+  T2H_REQUIRE(C == 512, "t2h_sample_head: C=%d unsupported (512)", C);
+  const size_t lds = (size_t)(n_class + 8) * sizeof(float);
+  hipLaunchKernelGGL(sample_head_kernel<512>, dim3(n), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), hidden, lnf_gamma, lnf_beta, w_head, expo,
+                     changes, tex, head, 1.0f / temp, x_t, out_idx, n_class);
+  T2H_CHECK_LAUNCH("t2h_sample_head");
+  return T2H_OK;
+}

@@ -1,0 +1,289 @@
+"""Host-side composition of the HIP kernels into the stages of the sampling
+path: segm tokenizer (T), index sampler (S),
+feed-forward index refinement (R), hierarchical decode (D), pose front-end (P).
+
+Everything here is batched over images (the reference decodes one image at a
+time, models/sample_model.py:220; every op is per-sample so batching is exact)
+and keeps activations as NHWC pixel rows [B*H*W, C] / token rows [B*T, C] in
+HBM.  PyTorch only allocates tensors and provides the stream.
+"""
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, PRO_NONE, PRO_SWISH
+
+
+# ---------------------------------------------------------------- VQGAN stacks
+
+
+class VQGANStack:
+    """Encoder / Decoder / DecoderRes forward over packed params `P` (see
+    weights.pack_vqgan) under prefix `name`."""
+
+    def __init__(self, P, name, desc):
+        self.P, self.name, self.desc = P, name, desc
+
+    def _gn(self, x, pfx, n_img, hw):
+        P = self.P
+        return ops.groupnorm_tables(x, P[f'{pfx}.g'], P[f'{pfx}.b'], n_img, hw)
+
+    def resblock(self, x, pfx, n_img, h, w):
+        """ResnetBlock.forward (vqgan_arch.py:597-617): both GroupNorm+swish are
+        fused into the following conv's operand load, bias + skip into its
+        epilogue."""
+        P = self.P
+        cin = P[f'{pfx}.conv1.w'].shape[1] // 9
+        cout = P[f'{pfx}.conv1.w'].shape[0]
+        sc, sh = self._gn(x, f'{pfx}.norm1', n_img, h * w)
+        t = ops.conv3x3(x, P[f'{pfx}.conv1.w'], n_img, h, w, cin, bias=P[f'{pfx}.conv1.b'],
+                        pro=(sc, sh, PRO_SWISH))
+        sc, sh = self._gn(t, f'{pfx}.norm2', n_img, h * w)
+        skip = x
+        if f'{pfx}.nin.w' in P:
+            skip = ops.gemm(x, P[f'{pfx}.nin.w'], bias=P[f'{pfx}.nin.b'])
+        return ops.conv3x3(t, P[f'{pfx}.conv2.w'], n_img, h, w, cout, bias=P[f'{pfx}.conv2.b'],
+                           pro=(sc, sh, PRO_SWISH), residual=skip)
+
+    def attnblock(self, x, pfx, n_img, n):
+        """AttnBlock.forward (vqgan_arch.py:636-661)."""
+        P = self.P
+        c = x.shape[1]
+        sc, sh = self._gn(x, f'{pfx}.norm', n_img, n)
+        qkv = ops.gemm(x, P[f'{pfx}.qkv.w'], bias=P[f'{pfx}.qkv.b'], pro=(sc, sh, n, PRO_NONE))
+        q3 = qkv.view(n_img, n, 3 * c)
+        s = torch.empty((n_img, n, n), device=x.device, dtype=torch.float32)
+        ops.bgemm(q3[:, :, :c], q3[:, :, c:2 * c], s, alpha=float(int(c)**(-0.5)))
+        ops.softmax_rows_(s)
+        o = torch.empty((n_img, n, c), device=x.device, dtype=torch.float32)
+        ops.bgemm(s, q3[:, :, 2 * c:], o, b_trans=True)
+        return ops.gemm(o.view(n_img * n, c), P[f'{pfx}.proj.w'], bias=P[f'{pfx}.proj.b'], residual=x)
+
+    def _mid(self, h, n_img, hh, ww):
+        nm = self.name
+        h = self.resblock(h, f'{nm}.mid.block_1', n_img, hh, ww)
+        h = self.attnblock(h, f'{nm}.mid.attn_1', n_img, hh * ww)
+        return self.resblock(h, f'{nm}.mid.block_2', n_img, hh, ww)
+
+    def _conv(self, x, pfx, n_img, h, w, mode='same', **kw):
+        P = self.P
+        cin = P[f'{pfx}.w'].shape[1] // 9
+        return ops.conv3x3(x, P[f'{pfx}.w'], n_img, h, w, cin, bias=P[f'{pfx}.b'], mode=mode, **kw)
+
+    def encode(self, x, n_img, h, w):
+        """Encoder.forward (vqgan_arch.py:892-919); x rows [n_img*h*w, Cin_pad]."""
+        nm = self.name
+        t = self._conv(x, f'{nm}.conv_in', n_img, h, w)
+        for lv in self.desc['levels']:
+            assert lv['kind'] == 'down'
+            for b, blk in enumerate(lv['blocks']):
+                t = self.resblock(t, f"{nm}.down.{lv['level']}.block.{b}", n_img, h, w)
+                if blk['attn']:
+                    t = self.attnblock(t, f"{nm}.down.{lv['level']}.attn.{b}", n_img, h * w)
+            if lv['resample']:
+                t = self._conv(t, f"{nm}.down.{lv['level']}.downsample", n_img, h, w, mode='down')
+                h, w = h // 2, w // 2
+        t = self._mid(t, n_img, h, w)
+        sc, sh = self._gn(t, f'{nm}.norm_out', n_img, h * w)
+        return self._conv(t, f'{nm}.conv_out', n_img, h, w, pro=(sc, sh, PRO_SWISH)), h, w
+
+    def decode(self, z, n_img, h, w, bot_h=None):
+        """Decoder.forward (vqgan_arch.py:1000-1033).  `bot_h` is added in the
+        epilogue of the level-4 Upsample conv (:1021-1024)."""
+        nm = self.name
+        t = self._conv(z, f'{nm}.conv_in', n_img, h, w)
+        t = self._mid(t, n_img, h, w)
+        levels = [lv for lv in self.desc['levels'] if lv['kind'] == 'up']
+        for lv in sorted(levels, key=lambda d: -d['level']):
+            for b, blk in enumerate(lv['blocks']):
+                t = self.resblock(t, f"{nm}.up.{lv['level']}.block.{b}", n_img, h, w)
+                if blk['attn']:
+                    t = self.attnblock(t, f"{nm}.up.{lv['level']}.attn.{b}", n_img, h * w)
+            if lv['resample']:
+                res = bot_h if (lv['level'] == 4 and bot_h is not None) else None
+                t = self._conv(t, f"{nm}.up.{lv['level']}.upsample", n_img, h, w, mode='up',
+                               residual=res)
+                h, w = 2 * h, 2 * w
+            elif lv['level'] == 4 and bot_h is not None:
+                t = t + bot_h
+        sc, sh = self._gn(t, f'{nm}.norm_out', n_img, h * w)
+        return self._conv(t, f'{nm}.conv_out', n_img, h, w, pro=(sc, sh, PRO_SWISH)), h, w
+
+    def decode_res(self, z, n_img, h, w):
+        """DecoderRes.forward (vqgan_arch.py:1136-1151)."""
+        t = self._conv(z, f'{self.name}.conv_in', n_img, h, w)
+        return self._mid(t, n_img, h, w)
+
+
+# ---------------------------------------------------------------- transformer
+
+
+class SamplerNet:
+    """TransformerMultiHead.forward (models/archs/transformer_arch.py:249-273)
+    up to (not including) ln_f; ln_f + the routed head live in the sampling
+    tail kernel.  24 x [LN, QKV GEMM, flash MHA, proj GEMM(+res), LN, fc1
+    GEMM(+GELU), fc2 GEMM(+res)]."""
+
+    def __init__(self, P, desc, n_head, name='tf'):
+        self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
+        self._buf = {}
+
+    def _buffers(self, M, C, dev):
+        key = (M, C, str(dev))
+        if key not in self._buf:
+            e = lambda n: torch.empty((M, n), device=dev, dtype=torch.float32)
+            self._buf = {key: dict(x=e(C), h=e(C), qkv=e(3 * C), y=e(C), u=e(4 * C))}
+        return self._buf[key]
+
+    def hidden(self, idx, segm_tok, tex_tok):
+        P, nm = self.P, self.name
+        B, T = idx.shape
+        C = self.desc['C']
+        buf = self._buffers(B * T, C, idx.device)
+        x, h, qkv, y, u = buf['x'], buf['h'], buf['qkv'], buf['y'], buf['u']
+        ops.embed_sum4(idx, segm_tok, tex_tok, P[f'{nm}.tok_emb'], P[f'{nm}.pos_emb'],
+                       P[f'{nm}.segm_emb'], P[f'{nm}.tex_emb'], out=x)
+        for i in range(self.desc['n_layers']):
+            p = f'{nm}.{i}'
+            ops.layernorm(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], out=h)
+            ops.gemm(h, P[f'{p}.qkv.w'], out=qkv, bias=P[f'{p}.qkv.b'])
+            ops.mha_noncausal(qkv, B, T, self.n_head, out=y)
+            ops.gemm(y, P[f'{p}.proj.w'], out=x, bias=P[f'{p}.proj.b'], residual=x)
+            ops.layernorm(x, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], out=h)
+            ops.gemm(h, P[f'{p}.fc1.w'], out=u, bias=P[f'{p}.fc1.b'], act=ACT_GELU)
+            ops.gemm(u, P[f'{p}.fc2.w'], out=x, bias=P[f'{p}.fc2.b'], residual=x)
+        return x
+
+    def logits(self, idx, segm_tok, tex_tok, heads=None):
+        """Full [B*T, 1024] logits per head (tests / API parity only; the
+        sampling loop never materialises them)."""
+        P, nm = self.P, self.name
+        x = self.hidden(idx, segm_tok, tex_tok)
+        xf = ops.layernorm(x, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'])
+        B, T = idx.shape
+        out = []
+        for hd in range(self.desc['n_heads']):
+            if heads is not None and hd not in heads:
+                out.append(None)
+                continue
+            out.append(ops.gemm(xf, P[f'{nm}.heads'][hd]).view(B, T, -1))
+        return out
+
+
+class TorchDeviceNoise:
+    """Default noise source: consumes torch's global generator of the GPU
+    exactly like the reference does (rand per step; one full [B*T, 1024]
+    exponential_ per ACTIVE head, the draw Categorical.sample() makes inside
+    multinomial) so identical seeds give identical tokens."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def uniform(self, step, shape):
+        return torch.rand(shape, device=self.device)
+
+    def exponential(self, step, head, shape):
+        return torch.empty(shape, device=self.device).exponential_(1.0)
+
+
+def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise=None,
+                  n_books=18):
+    """BaseSampleModel.sample_fn (models/sample_model.py:256-328) on device.
+
+    Per step: one tiny kernel does the mask algebra and counts the changed
+    tokens per texture head; ONE host read of those 18 counters decides which
+    heads draw noise (the reference's data-dependent `if`, :301-302, which
+    gates RNG consumption) -- it is issued before the transformer launches so
+    the host wait overlaps the GPU work; then the texture-routed sampling tail
+    runs once per active head.  Returns int64 [18, B*T] (-1 off-texture)."""
+    P, nm = net.P, net.name
+    B, T = segm_tok.shape
+    dev = segm_tok.device
+    noise = noise or TorchDeviceNoise(dev)
+    n = B * T
+    x_t = torch.full((B, T), mask_id, dtype=torch.int64, device=dev)
+    unmasked = torch.zeros(n, dtype=torch.uint8, device=dev)
+    changes = torch.zeros(n, dtype=torch.uint8, device=dev)
+    out = torch.full((n_books, n), -1, dtype=torch.int64, device=dev)
+    counts = torch.zeros(n_books, dtype=torch.int32, device=dev)
+    counts_host = torch.zeros(n_books, dtype=torch.int32).pin_memory()
+    tex_flat = tex_tok.reshape(-1).contiguous()
+    n_class = P[f'{nm}.heads'].shape[1]
+    ev = torch.cuda.Event()
+    for t in range(sample_steps, 0, -1):
+        rnd = noise.uniform(t, (B, T)).to(dev, torch.float32).contiguous()
+        counts.zero_()
+        ops.unmask_step(rnd, t, unmasked, changes, tex_flat, counts)
+        counts_host.copy_(counts, non_blocking=True)
+        ev.record()
+        hidden = net.hidden(x_t, segm_tok, tex_tok)
+        ev.synchronize()
+        active = torch.nonzero(counts_host).flatten().tolist()
+        for cb in active:
+            expo = noise.exponential(t, cb, (n, n_class)).to(dev, torch.float32).contiguous()
+            ops.sample_head(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'][cb], expo,
+                            changes, tex_flat, cb, temp, x_t, out[cb])
+    return out
+
+
+# ---------------------------------------------------------------- UNet + heads
+
+
+class UNetStack:
+    """UNet.forward / ShapeUNet.forward (models/archs/unet_arch.py:470-481,
+    657-674) with BN folded; returns the full-resolution decoder output
+    (dec_outs[4], the only one the heads read, in_index=4)."""
+
+    def __init__(self, P, name, desc):
+        self.P, self.name, self.desc = P, name, desc
+
+    def _cm(self, x, pfx, n_img, h, w, **kw):
+        P = self.P
+        cin = P[f'{pfx}.w'].shape[1] // 9
+        return ops.conv3x3(x, P[f'{pfx}.w'], n_img, h, w, cin, bias=P[f'{pfx}.b'], act=ACT_RELU, **kw)
+
+    def _attr_bias_map(self, attr, pfx, n_img, h, w):
+        """Per-pixel bias of the spatially constant attribute channels: sum over
+        the taps that fall inside the image of (W_attr[tap] @ attr[b])."""
+        P = self.P
+        wattr = P[f'{pfx}.wattr']  # [Cout, 9, A]
+        cout = wattr.shape[0]
+        tapc = ops.gemm(attr, wattr.view(cout * 9, -1)).view(n_img, cout, 9)  # [B, Cout, 9]
+        dev = attr.device
+        ys, xs = torch.arange(h, device=dev), torch.arange(w, device=dev)
+        valid = torch.zeros((9, h, w), device=dev, dtype=torch.float32)
+        for dy in range(3):
+            for dx in range(3):
+                vy = ((ys + dy - 1) >= 0) & ((ys + dy - 1) < h)
+                vx = ((xs + dx - 1) >= 0) & ((xs + dx - 1) < w)
+                valid[dy * 3 + dx] = (vy[:, None] & vx[None, :]).float()
+        # 9 validity patterns only; plain PyTorch glue on a [B,Cout,9]x[9,HW] product
+        return torch.einsum('bct,tp->bpc', tapc, valid.view(9, h * w)).reshape(n_img * h * w, cout).contiguous()
+
+    def forward(self, x, n_img, h, w, attr=None):
+        nm = self.name
+        n_st = len(self.desc['stages'])
+        skips = []
+        for i in range(n_st):
+            if i != 0:
+                x = ops.maxpool2(x, n_img, h, w)
+                h, w = h // 2, w // 2
+            if attr is not None:
+                bm = self._attr_bias_map(attr, f'{nm}.enc.{i}.0', n_img, h, w)
+                x = self._cm(x, f'{nm}.enc.{i}.0', n_img, h, w, residual=bm, res_pre=True)
+            else:
+                x = self._cm(x, f'{nm}.enc.{i}.0', n_img, h, w)
+            x = self._cm(x, f'{nm}.enc.{i}.1', n_img, h, w)
+            skips.append((x, h, w))
+        for d in reversed(range(n_st - 1)):
+            skip, sh_, sw_ = skips[d]
+            up = ops.bilinear_up2(x, n_img, h, w)
+            h, w = 2 * h, 2 * w
+            P = self.P
+            cs = skip.shape[1]
+            cat = torch.empty((n_img * h * w, 2 * cs), device=x.device, dtype=torch.float32)
+            cat[:, :cs].copy_(skip)
+            ops.gemm(up, P[f'{nm}.dec.{d}.up.w'], out=cat[:, cs:], bias=P[f'{nm}.dec.{d}.up.b'],
+                     act=ACT_RELU)
+            x = self._cm(cat, f'{nm}.dec.{d}.0', n_img, h, w)
+            x = self._cm(x, f'{nm}.dec.{d}.1', n_img, h, w)
+        return x, h, w

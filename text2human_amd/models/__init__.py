@@ -1,0 +1,21 @@
+"""`create_model(opt)` factory -- drop-in for the reference's
+models/__init__.py:21-42 restricted to the two sampling model types."""
+import logging
+
+from .sample_model import (BaseSampleModel, SampleFromParsingModel,  # noqa: F401
+                           SampleFromPoseModel)
+
+_MODELS = {
+    'SampleFromParsingModel': SampleFromParsingModel,
+    'SampleFromPoseModel': SampleFromPoseModel,
+}
+
+
+def create_model(opt):
+    model_type = opt['model_type']
+    model_cls = _MODELS.get(model_type)
+    if model_cls is None:
+        raise ValueError(f'Model {model_type} is not found.')
+    model = model_cls(opt)
+    logging.getLogger('base').info(f'Model [{model.__class__.__name__}] is created.')
+    return model

@@ -1,0 +1,334 @@
+"""Thin tensor -> pointer wrappers over the C ABI (include/t2h_hip.h).
+
+PyTorch-ROCm is used for device memory, streams and nothing else: every
+function here checks dtype / device / contiguity, takes raw device pointers and
+the current HIP stream, and calls into libt2h_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+PRO_NONE, PRO_SWISH = 0, 1
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise TypeError(f'expected CUDA float32 tensor, got {t.dtype} on {t.device}')
+
+
+def _chk_i64(*ts):
+    for t in ts:
+        if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError('expected contiguous CUDA int64 tensor')
+
+
+def _rows(t):
+    """(ptr tensor, leading dim) of a 2-D row-major view (stride(1) == 1)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f'need a 2-D tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}')
+    return t.stride(0)
+
+
+def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=None,
+         b_trans=False):
+    """out[M,N] = act(alpha * pro(a)[M,K] @ w[N,K]^T + bias) + residual.
+
+    a, w, out, residual: 2-D views with unit inner stride (row stride free).
+    pro = (scale[n_img,K], shift[n_img,K], rows_per_img, pro_act).
+    b_trans: w is given as [K,N]."""
+    _chk_f32(a, w, out, bias, residual)
+    M, K = a.shape
+    N = w.shape[1] if b_trans else w.shape[0]
+    assert (w.shape[0] if b_trans else w.shape[1]) == K, (a.shape, w.shape)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.A, g.B, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.residual = residual.data_ptr() if residual is not None else None
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = _rows(a), _rows(w), _rows(out)
+    g.ldr = _rows(residual) if residual is not None else 0
+    g.a_mode, g.b_trans, g.epi_act, g.alpha = 0, int(b_trans), act, alpha
+    if pro is not None:
+        sc, sh, rows, pact = pro
+        _chk_f32(sc, sh)
+        g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
+        g.pro_rows, g.pro_ld, g.pro_act = rows, sc.shape[1], pact
+    g.batch = 1
+    check(_lib.load().t2h_gemm_f32(ctypes.byref(g), _stream()), 't2h_gemm_f32')
+    return out
+
+
+def bgemm(a, w, out, alpha=1.0, b_trans=False):
+    """Batched: a [b,M,K], w [b,N,K] (or [b,K,N] if b_trans), out [b,M,N]; 3-D
+    views with unit inner stride (batch / row strides free)."""
+    _chk_f32(a, w, out)
+    nb, M, K = a.shape
+    N = w.shape[2] if b_trans else w.shape[1]
+    g = GemmArgs()
+    g.A, g.B, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    assert a.stride(2) == 1 and w.stride(2) == 1 and out.stride(2) == 1
+    g.lda, g.ldb, g.ldc = a.stride(1), w.stride(1), out.stride(1)
+    g.strideA, g.strideB, g.strideC = a.stride(0), w.stride(0), out.stride(0)
+    g.batch, g.alpha, g.b_trans = nb, alpha, int(b_trans)
+    check(_lib.load().t2h_gemm_f32(ctypes.byref(g), _stream()), 't2h_gemm_f32(batched)')
+    return out
+
+
+def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=ACT_NONE,
+            pro=None, mode='same', res_pre=False):
+    """3x3 convolution of an NHWC image held as pixel rows x [n_img*hin*win, >=cin]
+    with packed weights w [Cout, 9*cin] ([tap][cin] order).
+
+    mode: 'same' (stride 1 pad 1), 'up' (nearest x2 then same conv),
+          'down' (zero-pad right/bottom by 1, stride 2)."""
+    _chk_f32(x, w, out, bias, residual)
+    if mode == 'same':
+        hout, wout, stride, pad, ups = hin, win, 1, 1, 0
+    elif mode == 'up':
+        hout, wout, stride, pad, ups = 2 * hin, 2 * win, 1, 1, 1
+    elif mode == 'down':
+        hout, wout, stride, pad, ups = hin // 2, win // 2, 2, 0, 0
+    else:
+        raise ValueError(mode)
+    M, N = n_img * hout * wout, w.shape[0]
+    assert w.shape[1] == 9 * cin and x.shape[0] == n_img * hin * win
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.A, g.B, g.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.residual = residual.data_ptr() if residual is not None else None
+    g.M, g.N, g.K = M, N, 9 * cin
+    g.lda, g.ldb, g.ldc = _rows(x), _rows(w), _rows(out)
+    g.ldr = _rows(residual) if residual is not None else 0
+    g.a_mode, g.epi_act, g.alpha, g.res_pre = 1, act, 1.0, int(res_pre)
+    g.Hin, g.Win, g.Cin, g.Hout, g.Wout = hin, win, cin, hout, wout
+    g.stride, g.pad, g.ups, g.batch = stride, pad, ups, 1
+    if pro is not None:
+        sc, sh, pact = pro
+        _chk_f32(sc, sh)
+        g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
+        g.pro_ld, g.pro_act = sc.shape[1], pact
+    check(_lib.load().t2h_gemm_f32(ctypes.byref(g), _stream()), 't2h_gemm_f32(conv)')
+    return out
+
+
+def layernorm(x, gamma, beta, out=None, eps=1e-5):
+    _chk_f32(x, gamma, beta, out)
+    assert x.is_contiguous()
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().t2h_layernorm_f32(_p(x), _p(gamma), _p(beta), _p(out), rows, C, eps, _stream()),
+          't2h_layernorm_f32')
+    return out
+
+
+def groupnorm_tables(x, gamma, beta, n_img, hw, groups=32, eps=1e-6):
+    """GroupNorm statistics of x [n_img*hw, C] -> (scale, shift) [n_img, C]."""
+    _chk_f32(x, gamma, beta)
+    C = gamma.shape[0]
+    lib = _lib.load()
+    ws = torch.empty(lib.t2h_groupnorm_workspace_bytes(n_img, hw, C) // 8, device=x.device,
+                     dtype=torch.float64)
+    scale = torch.empty((n_img, C), device=x.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    check(lib.t2h_groupnorm_tables_f32(_p(x), _rows(x), _p(gamma), _p(beta), _p(scale), _p(shift),
+                                       n_img, hw, C, groups, eps, _p(ws), _stream()),
+          't2h_groupnorm_tables_f32')
+    return scale, shift
+
+
+def softmax_rows_(x):
+    _chk_f32(x)
+    x2 = x.view(-1, x.shape[-1])
+    check(_lib.load().t2h_softmax_rows_f32(_p(x2), x2.shape[0], x2.shape[1], x2.stride(0), _stream()),
+          't2h_softmax_rows_f32')
+    return x
+
+
+def embed_sum4(idx, segm, tex, tok_emb, pos_emb, segm_emb, tex_emb, out=None):
+    _chk_i64(idx, segm, tex)
+    _chk_f32(tok_emb, pos_emb, segm_emb, tex_emb, out)
+    B, T = idx.shape
+    C = tok_emb.shape[1]
+    if out is None:
+        out = torch.empty((B * T, C), device=idx.device, dtype=torch.float32)
+    check(_lib.load().t2h_embed_sum4_f32(_p(idx), _p(segm), _p(tex), _p(tok_emb), _p(pos_emb),
+                                         _p(segm_emb), _p(tex_emb), _p(out), B, T, C, _stream()),
+          't2h_embed_sum4_f32')
+    return out
+
+
+def mha_noncausal(qkv, B, T, n_head, out=None):
+    _chk_f32(qkv, out)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * n_head * 64)
+    if out is None:
+        out = torch.empty((B * T, n_head * 64), device=qkv.device, dtype=torch.float32)
+    check(_lib.load().t2h_mha_noncausal_f32(_p(qkv), _p(out), B, T, n_head, _stream()),
+          't2h_mha_noncausal_f32')
+    return out
+
+
+def unmask_step(rand, t, unmasked, changes, tex, head_count):
+    _chk_f32(rand)
+    n = rand.numel()
+    check(_lib.load().t2h_unmask_step(_p(rand), int(t), _p(unmasked), _p(changes), _p(tex),
+                                      _p(head_count), n, _stream()), 't2h_unmask_step')
+
+
+def sample_head(hidden, lnf_g, lnf_b, w_head, expo, changes, tex, head, temp, x_t, out_idx):
+    _chk_f32(hidden, lnf_g, lnf_b, w_head, expo)
+    n, C = hidden.shape
+    n_class = w_head.shape[0]
+    assert expo.shape == (n, n_class) and expo.is_contiguous() and w_head.is_contiguous()
+    check(_lib.load().t2h_sample_head(_p(hidden), _p(lnf_g), _p(lnf_b), _p(w_head), _p(expo),
+                                      _p(changes), _p(tex), int(head), float(temp), _p(x_t),
+                                      _p(out_idx), n, C, n_class, _stream()), 't2h_sample_head')
+
+
+def vq_l2_argmin(z, codebook):
+    _chk_f32(z, codebook)
+    assert z.is_contiguous() and codebook.is_contiguous()
+    n, d = z.shape
+    idx = torch.empty((n, ), device=z.device, dtype=torch.int64)
+    check(_lib.load().t2h_vq_l2_argmin_f32(_p(z), _p(codebook), _p(idx), n, codebook.shape[0], d,
+                                           _stream()), 't2h_vq_l2_argmin_f32')
+    return idx
+
+
+def codebook_gather_tex(idx_lists, tex, books):
+    """idx_lists [18, n] i64, tex [n] i64, books [18, n_e, e_dim] -> [n, e_dim]."""
+    _chk_i64(idx_lists, tex)
+    _chk_f32(books)
+    nb, n_e, e_dim = books.shape
+    n = tex.numel()
+    out = torch.empty((n, e_dim), device=books.device, dtype=torch.float32)
+    check(_lib.load().t2h_codebook_gather_tex_f32(_p(idx_lists), _p(tex), _p(books), _p(out), n, nb,
+                                                  n_e, e_dim, _stream()),
+          't2h_codebook_gather_tex_f32')
+    return out
+
+
+def codebook_gather_fold(idx_lists, tex, books, B, h, w):
+    """books [18, n_e, C*4] -> NHWC rows [B*2h*2w, C]."""
+    _chk_i64(idx_lists, tex)
+    _chk_f32(books)
+    nb, n_e, e4 = books.shape
+    C = e4 // 4
+    out = torch.empty((B * 2 * h * 2 * w, C), device=books.device, dtype=torch.float32)
+    check(_lib.load().t2h_codebook_gather_fold_f32(_p(idx_lists), _p(tex), _p(books), _p(out), B, h, w,
+                                                   nb, n_e, C, _stream()),
+          't2h_codebook_gather_fold_f32')
+    return out
+
+
+def routed_head_argmax(feat, w, b, tex, n_heads, cf, n_class):
+    """feat [n, n_heads*cf]; w [n_heads, n_class, cf]; b [n_heads, n_class]
+    -> out_lists [n_heads, n] i64 (-1 off-texture)."""
+    _chk_f32(feat, w, b)
+    _chk_i64(tex)
+    n = feat.shape[0]
+    out = torch.empty((n_heads, n), device=feat.device, dtype=torch.int64)
+    check(_lib.load().t2h_routed_head_argmax(_p(feat), _rows(feat), _p(w), _p(b), _p(tex), _p(out), n,
+                                             n_heads, cf, n_class, _stream()),
+          't2h_routed_head_argmax')
+    return out
+
+
+def onehot_nhwc(segm, n_cls, cpad):
+    _chk_f32(segm)
+    n_pix = segm.numel()
+    out = torch.empty((n_pix, cpad), device=segm.device, dtype=torch.float32)
+    check(_lib.load().t2h_onehot_nhwc_f32(_p(segm.contiguous()), _p(out), n_pix, n_cls, cpad, _stream()),
+          't2h_onehot_nhwc_f32')
+    return out
+
+
+def nchw_to_nhwc(x, cpad=None):
+    """x [B,C,H,W] -> rows [B*H*W, cpad or C] (extra channels zero)."""
+    _chk_f32(x)
+    B, C, H, W = x.shape
+    ld = cpad or C
+    out = (torch.zeros if ld != C else torch.empty)((B * H * W, ld), device=x.device,
+                                                   dtype=torch.float32)
+    check(_lib.load().t2h_nchw_to_nhwc_f32(_p(x.contiguous()), _p(out), B, C, H * W, ld, _stream()),
+          't2h_nchw_to_nhwc_f32')
+    return out
+
+
+def nhwc_to_nchw(x, B, H, W, C=None):
+    _chk_f32(x)
+    C = C or x.shape[1]
+    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    check(_lib.load().t2h_nhwc_to_nchw_f32(_p(x), _rows(x), _p(out), B, C, H * W, _stream()),
+          't2h_nhwc_to_nchw_f32')
+    return out
+
+
+def maxpool2(x, B, H, W):
+    _chk_f32(x)
+    C = x.shape[1]
+    out = torch.empty((B * (H // 2) * (W // 2), C), device=x.device, dtype=torch.float32)
+    check(_lib.load().t2h_maxpool2_nhwc_f32(_p(x), _rows(x), _p(out), B, H, W, C, _stream()),
+          't2h_maxpool2_nhwc_f32')
+    return out
+
+
+def bilinear_up2(x, B, H, W):
+    _chk_f32(x)
+    assert x.is_contiguous()
+    C = x.shape[1]
+    out = torch.empty((B * 4 * H * W, C), device=x.device, dtype=torch.float32)
+    check(_lib.load().t2h_bilinear_up2_nhwc_f32(_p(x), _p(out), B, H, W, C, _stream()),
+          't2h_bilinear_up2_nhwc_f32')
+    return out
+
+
+def argmax_rows(x, n=None):
+    _chk_f32(x)
+    rows = x.shape[0]
+    n = n or x.shape[1]
+    out = torch.empty((rows, ), device=x.device, dtype=torch.int64)
+    check(_lib.load().t2h_argmax_rows_f32(_p(x), _rows(x), _p(out), rows, n, _stream()),
+          't2h_argmax_rows_f32')
+    return out
+
+
+def image_epilogue(dec, B, H, W, want_u8=False):
+    """dec rows [B*H*W, >=3] -> (img f32 [B,3,H,W] in [0,1], u8 [B,H,W,3] or None)."""
+    _chk_f32(dec)
+    img = torch.empty((B, 3, H, W), device=dec.device, dtype=torch.float32)
+    u8 = torch.empty((B, H, W, 3), device=dec.device, dtype=torch.uint8) if want_u8 else None
+    check(_lib.load().t2h_image_epilogue(_p(dec), _rows(dec), _p(img), _p(u8), B, H * W, _stream()),
+          't2h_image_epilogue')
+    return img, u8
+
+
+def texture_map(segm, upper, lower, outer):
+    """segm i64 [B,1,H,W] -> f32 mask [B,1,H,W]."""
+    _chk_i64(segm, upper, lower, outer)
+    B = segm.shape[0]
+    hw = segm.numel() // B
+    mask = torch.empty(segm.shape, device=segm.device, dtype=torch.float32)
+    check(_lib.load().t2h_texture_map(_p(segm), _p(upper), _p(lower), _p(outer), _p(mask), B, hw,
+                                      _stream()), 't2h_texture_map')
+    return mask

@@ -291,8 +291,11 @@ def module_schemas(opt):
                                        opt['segm_z_channels'],
                                        opt['segm_double_z'])
     s['segm_quantizer'] = OrderedDict(
+        # U(+-1) instead of the constructor's U(+-1/n_e): a spread like a trained
+        # codebook, so the argmin is decided far above fp32 rounding (with the
+        # init-time spread ~1e-3 the best/second-best gap is ~1 ulp of |z|^2).
         [('embedding.weight', ((opt['segm_n_embed'], opt['segm_embed_dim']),
-                               ('uniform', 1.0 / opt['segm_n_embed'])))])
+                               ('uniform', 1.0)))])
     s['segm_quant_conv'] = OrderedDict()
     _conv(s['segm_quant_conv'], '', opt['segm_embed_dim'], opt['segm_z_channels'], 1)
     s['guidance_encoder'] = unet_schema(opt['index_pred_encoder_in_channels'])
