@@ -81,6 +81,13 @@ typedef struct t2h_gemm_args {
 } t2h_gemm_args;
 
 int t2h_gemm_f32(const t2h_gemm_args* args, void* stream);
+/* id of the tile configuration the dispatcher picks for `args` (profiling
+ * labels): 0 64x64, 1 128x32, 2 128x64, 3 128x128, 4 128x64/K64, 5 128x128/K64,
+ * 6 128x64/8 waves, 7 128x64/K64/8 waves, 8 128x128/K64/8 waves */
+int t2h_gemm_tile_config(const t2h_gemm_args* args);
+/* tuning hook: force a configuration id for every following GEMM whose shape
+ * supports it (-1 = automatic); returns the previous setting */
+int t2h_gemm_force_config(int cfg);
 
 /* ------------------------------------------------------ normalisation ------
  * LayerNorm over the last dim (eps 1e-5): transformer_arch.py:80-81,93-95,231,270 */

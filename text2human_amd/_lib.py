@@ -40,6 +40,8 @@ SIGNATURES = {
     't2h_version': (ctypes.c_int, []),
     't2h_last_error': (ctypes.c_char_p, []),
     't2h_gemm_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp]),
+    't2h_gemm_tile_config': (ctypes.c_int, [ctypes.POINTER(GemmArgs)]),
+    't2h_gemm_force_config': (ctypes.c_int, [ctypes.c_int]),
     't2h_layernorm_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
     't2h_groupnorm_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32]),
     't2h_groupnorm_tables_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
@@ -81,6 +83,10 @@ def load():
         raise T2HError(
             f'{LIB_PATH} not found: build it with `python -m text2human_amd.build` '
             '(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback.')
+    # PyTorch-ROCm bundles its own libamdhip64.so (same SONAME).  Load torch FIRST so
+    # that this library binds to the HIP runtime torch already initialised -- the
+    # streams and device pointers handed over by torch belong to that runtime.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

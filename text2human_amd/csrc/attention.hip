@@ -28,7 +28,7 @@ constexpr int V_LD = 64;
 constexpr int O_LD = 68;
 
 __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
-                                                  float* __restrict__ y, int T, int C) {
+                                                  float* __restrict__ y, int T, int C, int n_head) {
   constexpr int SMEM_KV = KT * K_LD + KT * V_LD;
   constexpr int SMEM_O = 4 * 32 * O_LD;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_KV > SMEM_O ? SMEM_KV : SMEM_O];
@@ -37,8 +37,19 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * QB + wave * 32;
+  // XCD-aware mapping (workgroup id % 8 = XCD): the T/128 query tiles of one
+  // (batch, head) run on the same XCD and share its K/V through that L2.
+  int qt, head, b;
+  {
+    const int nqt = T / QB, total = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    qt = lin % nqt;
+    const int hb = lin / nqt;
+    head = hb % n_head;
+    b = hb / n_head;
+  }
+  const int q0 = qt * QB + wave * 32;
   const int ld = 3 * C;
   const float* base = qkv + (int64_t)b * T * ld + head * HD;
 
@@ -166,8 +177,8 @@ extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int3
   T2H_REQUIRE(T > 0 && T % QB == 0, "t2h_mha_noncausal_f32: T=%d must be a multiple of %d", T, QB);
   T2H_REQUIRE(t2h_aligned16(qkv) && t2h_aligned16(y), "t2h_mha_noncausal_f32: 16-byte alignment");
   const int C = n_head * HD;
-  dim3 grid(T / QB, n_head, B), block(256);
-  hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv, y, T, C);
+  dim3 grid((T / QB) * n_head * B), block(256);
+  hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv, y, T, C, n_head);
   T2H_CHECK_LAUNCH("t2h_mha_noncausal_f32");
   return T2H_OK;
 }

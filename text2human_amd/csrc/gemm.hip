@@ -5,29 +5,28 @@
 // One kernel family serves every dense contraction of the Text2Human sampling
 // path (see include/t2h_hip.h).  Design (MI355X-first):
 //   * v_mfma_f32_32x32x2_f32: exact-fp32 fma chains at the 157 TFLOP/s matrix
-//     rate; a 256-thread workgroup = 4 waves (one per SIMD), each wave owns a
-//     (BM/WARPS_M) x (BN/WARPS_N) tile of 32x32 accumulators.
-//   * K is walked in tiles of 32.  The MFMA k-pair of step s is (s, 16+s)
-//     inside the tile -- any fixed k permutation is legal as long as A and B
-//     agree -- so that every lane reads its 16 k values as four 16-byte
-//     ds_read_b128 (lane half h reads k = 16h .. 16h+15).
-//   * LDS rows are padded to 36 floats (9 x 16-B slots, odd): the four 16-lane
-//     groups of a ds_read_b128 hit 16 distinct slots -> conflict free.
+//     rate; a workgroup = 4 or 8 waves, each wave owns a (BM/WARPS_M) x
+//     (BN/WARPS_N) tile of 32x32 accumulators.
+//   * K is walked in tiles of BK (32 or 64).  The MFMA k-pair of step s is
+//     (s, BK/2+s) inside the tile -- any fixed k permutation is legal as long
+//     as A and B agree -- so that every lane reads its k values as 16-byte
+//     ds_read_b128 (lane half h reads k = h*BK/2 .. h*BK/2+BK/2-1).
+//   * LDS rows are padded to BK+4 floats (an odd number of 16-B slots): the
+//     four 16-lane groups of a ds_read_b128 hit 16 distinct slots -> conflict
+//     free.
 //   * global -> register -> LDS staging, double-buffered LDS, ONE barrier per
-//     K tile; next tile's global loads are issued before the MFMA block so HBM
-//     / L2 latency hides under ~2-4k cycles of matrix work.
+//     K tile; the next tile's global loads are issued before the MFMA block so
+//     HBM / L2 latency hides under the tile's matrix work (BK/2 x TM x TN MFMAs
+//     of 64 cycles each per wave).
 //   * conv mode builds the im2col operand on the fly from an NHWC image
-//     (K = [tap][cin], Cin % 32 == 0 so a K tile never straddles a tap), with
+//     (K = [tap][cin], Cin % BK == 0 so a K tile never straddles a tap), with
 //     nearest-x2 upsample / stride-2 asymmetric-pad variants folded into the
-//     coordinate math and GroupNorm-apply + swish folded into the operand load
-//     (per-(image,channel) scale/shift tables) -- zero padding is applied AFTER
-//     the activation, as the reference pads the activated tensor.
+//     coordinate math and GroupNorm-apply + swish folded into the operand
+//     staging (per-(image,channel) scale/shift tables) -- zero padding is
+//     applied AFTER the activation, as the reference pads the activated tensor.
 #include "common.h"
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int LDS_LD = 36;
 
 __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -46,14 +45,36 @@ __device__ __forceinline__ f32x4 prologue4(f32x4 v, const float* sc, const float
   return v;
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int AMODE, bool PRO, bool BTRANS>
-__global__ __launch_bounds__(256) void gemm_kernel(const t2h_gemm_args p) {
-  static_assert(WARPS_M * WARPS_N == 4, "4 waves per workgroup");
+#ifdef T2H_GEMM_TIMING
+__device__ long long* g_timing_buf = nullptr;  // debug builds only (tools/gemm_timing.py)
+#endif
+
+// Register staging set of one K tile (global -> registers -> LDS).
+template <int A_F4, int B_F4>
+struct Stage {
+  f32x4 a[A_F4];
+  f32x4 b[B_F4];
+  f32x4 sc, sh;    // PRO == 1: this thread's channel-quad scale / shift for the tile
+  unsigned valid;  // PRO == 1: bit i set <=> a[i] is a real element (not zero padding)
+};
+
+// PRO: 0 none; 1 prologue with one image per workgroup (rows_per_image % BM == 0):
+// raw values stay in registers and are transformed when they are written to LDS,
+// so the global loads are never waited for early; 2 generic prologue (a workgroup
+// may straddle images): transformed right after the load.
+template <int BM, int BN, int BK, int WARPS_M, int WARPS_N, int AMODE, int PRO, bool BTRANS>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_gemm_args p) {
+  constexpr int NT = 64 * WARPS_M * WARPS_N;
+  constexpr int LDS_LD = BK + 4;
+  constexpr int KQ = BK / 4;  // float4 per tile row
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
-  constexpr int A_F4 = BM / 32;  // float4 loads per thread for one A tile
-  constexpr int B_F4 = BN / 32;
+  constexpr int RPP = NT / KQ;          // tile rows staged per pass
+  constexpr int A_F4 = BM / RPP;        // float4 loads per thread for one A tile
+  constexpr int B_F4 = BN / RPP;
+  static_assert(A_F4 >= 1 && B_F4 >= 1 && BM % RPP == 0 && BN % RPP == 0, "bad staging shape");
+  using StageT = Stage<A_F4, B_F4>;
 
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
   float* const As = smem;
@@ -63,24 +84,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(const t2h_gemm_args p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
   const int wm0 = (wave / WARPS_N) * WM, wn0 = (wave % WARPS_N) * WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int64_t zb = blockIdx.z;
+  // XCD-aware tile mapping.  Workgroup b is dispatched to XCD b % 8 (8 XCDs,
+  // private 4 MiB L2 each, 32 CUs).  Give every XCD a CONTIGUOUS range of the
+  // row-major (m-tile, n-tile) sequence so that the workgroups that run together
+  // on one XCD share their A rows / B columns through that XCD's L2 instead of
+  // every XCD streaming the whole A matrix (bijective for any tile count).
+  const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int total = nbx * nby, b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3, q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int mt = lin / nbx;
+    m0 = mt * BM;
+    n0 = (lin - mt * nbx) * BN;
+  }
+  const int64_t zb = blockIdx.y;
   const float* __restrict__ Ag = p.A + zb * p.strideA;
   const float* __restrict__ Bg = p.B + zb * p.strideB;
   float* __restrict__ Cg = p.C + zb * p.strideC;
 
-  const int col4 = tid & 7, row0 = tid >> 3;
+  const int col4 = tid % KQ, row0 = tid / KQ;
 
   // ---- per-thread A row bookkeeping
   int64_t a_off[A_F4];  // plain: element offset of (row, col4*4); conv: image base pixel
   int a_y[A_F4], a_x[A_F4], a_img[A_F4];
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
-    const int m = m0 + row0 + 32 * i;
+    const int m = m0 + row0 + RPP * i;
     const bool ok = m < p.M;
     if (AMODE == 0) {
       a_off[i] = ok ? (int64_t)m * p.lda + col4 * 4 : -1;
-      a_img[i] = (PRO && ok) ? m / p.pro_rows : 0;
+      a_img[i] = (PRO == 2 && ok) ? m / p.pro_rows : 0;
       a_y[i] = a_x[i] = 0;
     } else {
       const int hw = p.Hout * p.Wout;
@@ -95,88 +130,104 @@ __global__ __launch_bounds__(256) void gemm_kernel(const t2h_gemm_args p) {
   }
   const int Hlim = (AMODE == 1) ? (p.Hin << p.ups) : 0;
   const int Wlim = (AMODE == 1) ? (p.Win << p.ups) : 0;
+  // PRO == 1: the whole workgroup lies in one image
+  const int64_t img0_tbl =
+      (PRO == 1) ? (int64_t)(m0 / (AMODE == 0 ? p.pro_rows : p.Hout * p.Wout)) * p.pro_ld : 0;
 
-  f32x4 a_reg[A_F4], b_reg[B_F4];
+  StageT st;
+  st.valid = 0u;
 
-  auto load_tiles = [&](int kt) {
-    const int k0 = kt * BK;
-    if (AMODE == 0) {
-#pragma unroll
-      for (int i = 0; i < A_F4; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (a_off[i] >= 0) {
-          v = *reinterpret_cast<const f32x4*>(Ag + a_off[i] + k0);
-          if (PRO) {
-            const int64_t t = (int64_t)a_img[i] * p.pro_ld + k0 + col4 * 4;
-            v = prologue4(v, p.pro_scale + t, p.pro_shift + t, p.pro_act);
-          }
-        }
-        a_reg[i] = v;
-      }
-    } else {
-      const int tap = k0 / p.Cin;
-      const int c0 = k0 - tap * p.Cin;
-      const int dy = tap / 3, dx = tap - 3 * dy;
-#pragma unroll
-      for (int i = 0; i < A_F4; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        int iy = a_y[i] + dy, ix = a_x[i] + dx;
-        if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
-          iy >>= p.ups;
-          ix >>= p.ups;
-          const int64_t pix = a_off[i] + (int64_t)iy * p.Win + ix;
-          v = *reinterpret_cast<const f32x4*>(Ag + pix * p.lda + c0 + col4 * 4);
-          if (PRO) {
-            const int64_t t = (int64_t)a_img[i] * p.pro_ld + c0 + col4 * 4;
-            v = prologue4(v, p.pro_scale + t, p.pro_shift + t, p.pro_act);
-          }
-        }
-        a_reg[i] = v;
-      }
+  // ---- staging "pieces": one float4 per piece, so that the main loop can issue
+  // them one at a time in the shadow of individual MFMAs.
+  struct TileK {  // wave-uniform description of K tile kt
+    int k0, c0, dy, dx;
+  };
+  auto tile_k = [&](int kt) {
+    TileK t;
+    t.k0 = kt * BK;
+    t.c0 = t.dy = t.dx = 0;
+    if (AMODE == 1) {
+      const int tap = t.k0 / p.Cin;
+      t.c0 = t.k0 - tap * p.Cin;
+      t.dy = tap / 3;
+      t.dx = tap - 3 * t.dy;
     }
-    if (!BTRANS) {
+    return t;
+  };
+  // Loads are UNCONDITIONAL from clamped (always valid) addresses; validity is
+  // tracked in bit masks and applied when the piece is written to LDS, so the
+  // main loop has no exec-masked branches around its global loads.
+  unsigned b_ok = 0u;
 #pragma unroll
-      for (int i = 0; i < B_F4; ++i) {
-        const int n = n0 + row0 + 32 * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.N) v = *reinterpret_cast<const f32x4*>(Bg + (int64_t)n * p.ldb + k0 + col4 * 4);
-        b_reg[i] = v;
-      }
-    } else {
-      constexpr int NQ = BN / 4;        // float4 per k-row of the tile
-      constexpr int RPP = 256 / NQ;     // k-rows per pass
-      const int n4 = tid % NQ, kr = tid / NQ;
-#pragma unroll
-      for (int i = 0; i < B_F4; ++i) {
-        const int k = k0 + kr + i * RPP;
-        const int n = n0 + n4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.N) v = *reinterpret_cast<const f32x4*>(Bg + (int64_t)k * p.ldb + n);
-        b_reg[i] = v;
-      }
+  for (int i = 0; i < B_F4; ++i) {
+    const bool ok = BTRANS ? (n0 + (tid % (BN / 4)) * 4 < p.N) : (n0 + row0 + RPP * i < p.N);
+    if (ok) b_ok |= 1u << i;
+  }
+  auto load_tbl = [&](const TileK& t) {  // PRO == 1 scale/shift of this tile
+    if (PRO == 1) {
+      const int c = (AMODE == 0 ? t.k0 : t.c0) + col4 * 4;
+      st.sc = *reinterpret_cast<const f32x4*>(p.pro_scale + img0_tbl + c);
+      st.sh = *reinterpret_cast<const f32x4*>(p.pro_shift + img0_tbl + c);
     }
   };
-
-  auto store_tiles = [&](int buf) {
-    float* Ad = As + buf * BM * LDS_LD;
-    float* Bd = Bs + buf * BN * LDS_LD;
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i)
-      *reinterpret_cast<f32x4*>(Ad + (row0 + 32 * i) * LDS_LD + col4 * 4) = a_reg[i];
-    if (!BTRANS) {
-#pragma unroll
-      for (int i = 0; i < B_F4; ++i)
-        *reinterpret_cast<f32x4*>(Bd + (row0 + 32 * i) * LDS_LD + col4 * 4) = b_reg[i];
+  auto load_a = [&](int i, const TileK& t) {
+    bool ok;
+    const float* src;
+    if (AMODE == 0) {
+      ok = a_off[i] >= 0;
+      src = Ag + (ok ? a_off[i] : (int64_t)(col4 * 4)) + t.k0;
     } else {
-      constexpr int NQ = BN / 4;
-      constexpr int RPP = 256 / NQ;
-      const int n4 = tid % NQ, kr = tid / NQ;
+      const int iy = a_y[i] + t.dy, ix = a_x[i] + t.dx;
+      ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+      const int cy = min(max(iy, 0), Hlim - 1) >> p.ups, cx = min(max(ix, 0), Wlim - 1) >> p.ups;
+      src = Ag + (a_off[i] + (int64_t)cy * p.Win + cx) * p.lda + t.c0 + col4 * 4;
+    }
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    st.valid = (st.valid & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+    if (PRO == 2) {  // generic prologue: transform now (waits for the load)
+      const int64_t o = (int64_t)a_img[i] * p.pro_ld + (AMODE == 0 ? t.k0 : t.c0) + col4 * 4;
+      v = prologue4(v, p.pro_scale + o, p.pro_shift + o, p.pro_act);
+    }
+    st.a[i] = v;
+  };
+  constexpr int NQ = BN / 4;    // BTRANS: float4 per k-row of the tile
+  constexpr int KPP = NT / NQ;  // BTRANS: k-rows per pass; BK / KPP == B_F4
+  auto load_b = [&](int i, const TileK& t) {
+    const bool ok = (b_ok >> i) & 1u;
+    const float* src;
+    if (!BTRANS) {
+      src = Bg + (int64_t)(ok ? n0 + row0 + RPP * i : 0) * p.ldb + t.k0 + col4 * 4;
+    } else {
+      src = Bg + (int64_t)(t.k0 + tid / NQ + i * KPP) * p.ldb + (ok ? n0 + (tid % NQ) * 4 : 0);
+    }
+    st.b[i] = *reinterpret_cast<const f32x4*>(src);
+  };
+  auto store_a = [&](int i, int buf) {
+    f32x4 v = st.a[i];
+    const bool ok = (st.valid >> i) & 1u;
 #pragma unroll
-      for (int i = 0; i < B_F4; ++i) {
-        const int kk = kr + i * RPP;           // logical k inside the tile
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bd[(n4 * 4 + e) * LDS_LD + kk] = b_reg[i][e];
+    for (int e = 0; e < 4; ++e) {
+      float x = v[e];
+      if (PRO == 1) {
+        x = fmaf(x, st.sc[e], st.sh[e]);
+        if (p.pro_act == 1) x = x / (1.0f + expf(-x));
       }
+      v[e] = ok ? x : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(As + buf * BM * LDS_LD + (row0 + RPP * i) * LDS_LD + col4 * 4) = v;
+  };
+  auto store_b = [&](int i, int buf) {
+    float* Bd = Bs + buf * BN * LDS_LD;
+    const bool ok = (b_ok >> i) & 1u;
+    f32x4 v = st.b[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+    if (!BTRANS) {
+      *reinterpret_cast<f32x4*>(Bd + (row0 + RPP * i) * LDS_LD + col4 * 4) = v;
+    } else {
+      const int kk = tid / NQ + i * KPP;  // logical k inside the tile
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Bd[((tid % NQ) * 4 + e) * LDS_LD + kk] = v[e];
     }
   };
 
@@ -188,39 +239,116 @@ __global__ __launch_bounds__(256) void gemm_kernel(const t2h_gemm_args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // ---- prologue: tile 0 -> LDS[0]; tile 1 -> registers
   const int nk = p.K / BK;
-  load_tiles(0);
-  store_tiles(0);
+  const int last = nk - 1;
+  {
+    const TileK t0 = tile_k(0);
+    load_tbl(t0);
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) load_a(i, t0);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) load_b(i, t0);
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) store_a(i, 0);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) store_b(i, 0);
+    const TileK t1 = tile_k(min(1, last));
+    load_tbl(t1);
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) load_a(i, t1);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) load_b(i, t1);
+  }
   __syncthreads();
 
+  // ---- main loop, software-pipelined and branch-free.  While tile kt is
+  // multiplied out of LDS[kt&1], the registers (tile kt+1, loaded during the
+  // previous iteration) are written to LDS[(kt+1)&1] and then refilled with
+  // tile kt+2 -- one float4 "piece" after each MFMA step in the second part of
+  // the step sequence, so the address math, ds_writes and global loads issue in
+  // the shadow of the 64-cycle MFMAs instead of between tiles.  Tail tiles are
+  // clamped (harmless duplicate loads / stores) so there is no divergent path.
+  constexpr int STEPS = BK / 2;             // MFMA k-steps per tile
+  constexpr int NPIECE = A_F4 + B_F4;       // float4 pieces per tile and direction
+  constexpr int FIRST = (2 * NPIECE <= STEPS) ? STEPS - 2 * NPIECE : 0;
+#ifdef T2H_GEMM_TIMING
+  const long long tm_begin = clock64();
+  long long tm_bar = 0;
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
-
-    const float* Ab = As + buf * BM * LDS_LD + (wm0 + l31) * LDS_LD + 16 * hh;
-    const float* Bb = Bs + buf * BN * LDS_LD + (wn0 + l31) * LDS_LD + 16 * hh;
+    const TileK tn = tile_k(min(kt + 2, last));
+    const float* Ab = As + buf * BM * LDS_LD + (wm0 + l31) * LDS_LD + (BK / 2) * hh;
+    const float* Bb = Bs + buf * BN * LDS_LD + (wn0 + l31) * LDS_LD + (BK / 2) * hh;
+    f32x4 af[2][TM], bf[2][TN];  // MFMA operand fragments, double-buffered over j
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 af[TM], bf[TN];
+    for (int ti = 0; ti < TM; ++ti) af[0][ti] = *reinterpret_cast<const f32x4*>(Ab + ti * 32 * LDS_LD);
 #pragma unroll
-      for (int ti = 0; ti < TM; ++ti)
-        af[ti] = *reinterpret_cast<const f32x4*>(Ab + ti * 32 * LDS_LD + 4 * j);
+    for (int tj = 0; tj < TN; ++tj) bf[0][tj] = *reinterpret_cast<const f32x4*>(Bb + tj * 32 * LDS_LD);
 #pragma unroll
-      for (int tj = 0; tj < TN; ++tj)
-        bf[tj] = *reinterpret_cast<const f32x4*>(Bb + tj * 32 * LDS_LD + 4 * j);
+    for (int j = 0; j < BK / 8; ++j) {
+      if (j + 1 < BK / 8) {  // next group's fragments fly under this group's MFMAs
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int ti = 0; ti < TM; ++ti)
+          af[(j + 1) & 1][ti] = *reinterpret_cast<const f32x4*>(Ab + ti * 32 * LDS_LD + 4 * (j + 1));
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj)
+          bf[(j + 1) & 1][tj] = *reinterpret_cast<const f32x4*>(Bb + tj * 32 * LDS_LD + 4 * (j + 1));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
           for (int tj = 0; tj < TN; ++tj)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ti][e], bf[tj][e],
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][ti][e], bf[j & 1][tj][e],
                                                                 acc[ti][tj], 0, 0, 0);
+        // auxiliary pieces pinned after MFMA step s: stores first, then loads
+        const int s = 4 * j + e;
+#pragma unroll
+        for (int q = 0; q < 2 * NPIECE; ++q) {
+          const int at = (2 * NPIECE <= STEPS) ? FIRST + q : (q * STEPS) / (2 * NPIECE);
+          if (at != s) continue;
+          __builtin_amdgcn_sched_barrier(0);
+          // piece order: B pieces first (the PRO tables are reloaded with the
+          // first A load, after every A store has consumed them), each register
+          // piece is stored and IMMEDIATELY re-loaded with the tile after next,
+          // which gives every global load ~a full tile period before its use.
+          const int pc = q >> 1;  // piece index: [0,B_F4) = B, [B_F4,NPIECE) = A
+#ifndef T2H_DBG_NOSTORE
+          if ((q & 1) == 0) {
+            if (pc < B_F4) store_b(pc, buf ^ 1);
+            else store_a(pc - B_F4, buf ^ 1);
+          }
+#endif
+#ifndef T2H_DBG_NOLOAD
+          if ((q & 1) == 1) {
+            if (pc < B_F4) load_b(pc, tn);
+            else {
+              load_a(pc - B_F4, tn);
+              if (pc == NPIECE - 1) load_tbl(tn);  // after the last A store used the old tables
+            }
+          }
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
-
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+#ifdef T2H_GEMM_TIMING
+    const long long tb0 = clock64();
+#endif
     __syncthreads();
+#ifdef T2H_GEMM_TIMING
+    tm_bar += clock64() - tb0;
+#endif
   }
+#ifdef T2H_GEMM_TIMING
+  if (g_timing_buf && blockIdx.x == 8 && tid == 0) {
+    g_timing_buf[0] = 0; g_timing_buf[1] = 0; g_timing_buf[2] = 0;
+    g_timing_buf[3] = tm_bar; g_timing_buf[4] = clock64() - tm_begin; g_timing_buf[5] = nk;
+  }
+#endif
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31,
   //      row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -247,31 +375,101 @@ __global__ __launch_bounds__(256) void gemm_kernel(const t2h_gemm_args p) {
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N>
+// ---- launch: every (tile, mode) combination
+template <int BM, int BN, int BK, int WARPS_M, int WARPS_N, bool FULL>
 int launch_cfg(const t2h_gemm_args& a, hipStream_t s) {
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch);
-  dim3 block(256);
+  dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), a.batch);
+  dim3 block(64 * WARPS_M * WARPS_N);
   const bool pro = a.pro_scale != nullptr;
+  const int rows_per_img = a.a_mode == 0 ? a.pro_rows : a.Hout * a.Wout;
+  const bool uniform = pro && rows_per_img % BM == 0;
+#define T2H_LAUNCH(AM, PR, BT)                                                                    \
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WARPS_M, WARPS_N, AM, PR, BT>), grid, block, 0, s, a)
   if (a.a_mode == 0) {
     if (a.b_trans) {
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WARPS_M, WARPS_N, 0, false, true>), grid, block, 0, s, a);
+      if constexpr (FULL) T2H_LAUNCH(0, 0, true); else return T2H_ERR_UNSUPPORTED;
+    } else if (uniform) {
+      T2H_LAUNCH(0, 1, false);
     } else if (pro) {
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WARPS_M, WARPS_N, 0, true, false>), grid, block, 0, s, a);
+      if constexpr (FULL) T2H_LAUNCH(0, 2, false); else return T2H_ERR_UNSUPPORTED;
     } else {
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WARPS_M, WARPS_N, 0, false, false>), grid, block, 0, s, a);
+      T2H_LAUNCH(0, 0, false);
     }
   } else {
-    if (pro) {
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WARPS_M, WARPS_N, 1, true, false>), grid, block, 0, s, a);
+    if (uniform) {
+      T2H_LAUNCH(1, 1, false);
+    } else if (pro) {
+      if constexpr (FULL) T2H_LAUNCH(1, 2, false); else return T2H_ERR_UNSUPPORTED;
     } else {
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WARPS_M, WARPS_N, 1, false, false>), grid, block, 0, s, a);
+      T2H_LAUNCH(1, 0, false);
     }
   }
+#undef T2H_LAUNCH
   T2H_CHECK_LAUNCH("t2h_gemm_f32");
   return T2H_OK;
 }
 
+// Tile configurations.  id -> (BM, BN, BK, waves).  0-3 support every mode
+// (b_trans, generic prologue); 4+ are the high-throughput variants.
+enum { CFG_64x64 = 0, CFG_128x32, CFG_128x64, CFG_128x128, CFG_128x64_K64, CFG_128x128_K64,
+       CFG_128x64_W8, CFG_128x64_K64_W8, CFG_128x128_K64_W8, CFG_COUNT };
+
+int cfg_bk(int cfg) {
+  return (cfg == CFG_128x64_K64 || cfg == CFG_128x128_K64 || cfg == CFG_128x64_K64_W8 ||
+          cfg == CFG_128x128_K64_W8) ? 64 : 32;
+}
+
+int launch_by_cfg(int cfg, const t2h_gemm_args& a, hipStream_t s) {
+  switch (cfg) {
+    case CFG_64x64: return launch_cfg<64, 64, 32, 2, 2, true>(a, s);
+    case CFG_128x32: return launch_cfg<128, 32, 32, 4, 1, true>(a, s);
+    case CFG_128x64: return launch_cfg<128, 64, 32, 2, 2, true>(a, s);
+    case CFG_128x128: return launch_cfg<128, 128, 32, 2, 2, true>(a, s);
+    case CFG_128x64_K64: return launch_cfg<128, 64, 64, 2, 2, false>(a, s);
+    case CFG_128x128_K64: return launch_cfg<128, 128, 64, 2, 2, false>(a, s);
+    case CFG_128x64_W8: return launch_cfg<128, 64, 32, 4, 2, false>(a, s);
+    case CFG_128x64_K64_W8: return launch_cfg<128, 64, 64, 4, 2, false>(a, s);
+    case CFG_128x128_K64_W8: return launch_cfg<128, 128, 64, 4, 2, false>(a, s);
+    default: return T2H_ERR_INVALID;
+  }
+}
+
+int g_force_cfg = -1;  // experiments / autotuning: t2h_gemm_force_config()
+
+// Tile choice.  256 CUs, <= 2 resident 4-wave workgroups per CU (LDS).
+int pick_cfg(const t2h_gemm_args& a) {
+  const bool pro = a.pro_scale != nullptr;
+  const int rows_per_img = a.a_mode == 0 ? a.pro_rows : a.Hout * a.Wout;
+  const bool fast_ok = !a.b_trans && (!pro || rows_per_img % 128 == 0);
+  if (g_force_cfg >= 0) {
+    const bool k_ok = a.K % cfg_bk(g_force_cfg) == 0 && (a.a_mode == 0 || a.Cin % cfg_bk(g_force_cfg) == 0);
+    if (k_ok && (g_force_cfg <= CFG_128x128 || fast_ok)) return g_force_cfg;
+  }
+  const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+  if (a.M <= 64) return CFG_64x64;
+  if (a.N <= 32) return CFG_128x32;
+  // plain GEMMs (transformer linears, 1x1 convs): 8 waves on a 128x64 tile keep two
+  // waves per SIMD even when the grid is only one workgroup per CU (measured best
+  // on every sampler shape at M = 4096, tools/gemm_bench.py)
+  if (a.a_mode == 0 && fast_ok) return CFG_128x64_W8;
+  if (a.N <= 64 || (a.N % 128 != 0 && a.N % 128 <= 64)) return CFG_128x64;
+  if (tiles128 >= 512) return CFG_128x128;
+  return CFG_128x64;
+}
+
 }  // namespace
+
+#ifdef T2H_GEMM_TIMING
+extern "C" int t2h_debug_set_timing_buffer(void* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing_buf), &dev_ptr, sizeof(void*));
+}
+#endif
+
+extern "C" int t2h_gemm_force_config(int cfg) {
+  const int old = g_force_cfg;
+  g_force_cfg = (cfg >= 0 && cfg < CFG_COUNT) ? cfg : -1;
+  return old;
+}
 
 extern "C" int t2h_gemm_f32(const t2h_gemm_args* args, void* stream) {
   T2H_REQUIRE(args != nullptr, "t2h_gemm_f32: args is NULL");
@@ -279,7 +477,7 @@ extern "C" int t2h_gemm_f32(const t2h_gemm_args* args, void* stream) {
   if (a.batch < 1) a.batch = 1;
   T2H_REQUIRE(a.A && a.B && a.C, "t2h_gemm_f32: NULL operand");
   T2H_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "t2h_gemm_f32: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-  T2H_REQUIRE(a.K % BK == 0, "t2h_gemm_f32: K=%d must be a multiple of %d", a.K, BK);
+  T2H_REQUIRE(a.K % 32 == 0, "t2h_gemm_f32: K=%d must be a multiple of 32", a.K);
   T2H_REQUIRE(a.lda % 4 == 0 && a.ldb % 4 == 0, "t2h_gemm_f32: lda/ldb must be multiples of 4");
   T2H_REQUIRE(t2h_aligned16(a.A) && t2h_aligned16(a.B), "t2h_gemm_f32: A/B must be 16-byte aligned");
   T2H_REQUIRE(a.strideA % 4 == 0 && a.strideB % 4 == 0, "t2h_gemm_f32: batch strides must be multiples of 4");
@@ -292,7 +490,7 @@ extern "C" int t2h_gemm_f32(const t2h_gemm_args* args, void* stream) {
   }
   if (a.a_mode == 1) {
     T2H_REQUIRE(!a.b_trans, "t2h_gemm_f32: conv with b_trans unsupported");
-    T2H_REQUIRE(a.Cin % BK == 0 && a.K == 9 * a.Cin, "t2h_gemm_f32: conv needs Cin %% 32 == 0 and K == 9*Cin (Cin=%d K=%d)", a.Cin, a.K);
+    T2H_REQUIRE(a.Cin % 32 == 0 && a.K == 9 * a.Cin, "t2h_gemm_f32: conv needs Cin %% 32 == 0 and K == 9*Cin (Cin=%d K=%d)", a.Cin, a.K);
     T2H_REQUIRE(a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0 && a.M % (a.Hout * a.Wout) == 0,
                 "t2h_gemm_f32: bad conv geometry");
     T2H_REQUIRE(a.stride >= 1 && a.ups >= 0 && a.ups <= 1, "t2h_gemm_f32: bad stride/ups");
@@ -300,11 +498,12 @@ extern "C" int t2h_gemm_f32(const t2h_gemm_args* args, void* stream) {
     T2H_REQUIRE(a.a_mode == 0, "t2h_gemm_f32: unknown a_mode %d", a.a_mode);
     if (a.b_trans) T2H_REQUIRE(a.N % 4 == 0, "t2h_gemm_f32: b_trans needs N %% 4 == 0");
   }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
-  if (a.M <= 64) return launch_cfg<64, 64, 2, 2>(a, s);
-  if (a.N <= 32) return launch_cfg<128, 32, 4, 1>(a, s);
-  if (a.N <= 64 || (a.N % 128 != 0 && a.N % 128 <= 64)) return launch_cfg<128, 64, 2, 2>(a, s);
-  if (tiles128 >= 512) return launch_cfg<128, 128, 2, 2>(a, s);
-  return launch_cfg<128, 64, 2, 2>(a, s);
+  return launch_by_cfg(pick_cfg(a), a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t2h_gemm_tile_config(const t2h_gemm_args* args) {
+  if (!args) return -1;
+  t2h_gemm_args a = *args;
+  if (a.batch < 1) a.batch = 1;
+  return pick_cfg(a);
 }

@@ -47,13 +47,15 @@ __global__ void unmask_step_kernel(const float* __restrict__ rnd, float thresh,
 // One workgroup per token row; rows that are not (changed && of this head's
 // texture) exit at once.  LN_f -> 512->n_class head (wave-cooperative dot
 // products, coalesced weight rows) -> exponential-race argmax.
+constexpr int SH_THREADS = 1024;
+
 template <int C>
-__global__ __launch_bounds__(256) void sample_head_kernel(
+__global__ __launch_bounds__(SH_THREADS) void sample_head_kernel(
     const float* __restrict__ hidden, const float* __restrict__ g, const float* __restrict__ bta,
     const float* __restrict__ w, const float* __restrict__ expo, const uint8_t* __restrict__ changes,
     const int64_t* __restrict__ tex, int head, float inv_temp, int64_t* __restrict__ x_t,
     int64_t* __restrict__ out_idx, int n_class) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // n_class logits + 2*4 reduce slots
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // n_class logits + 2*NW reduce slots
   const int row = blockIdx.x;
   if (!changes[row] || (int)tex[row] != head) return;
   constexpr int VPL = C / 256;
@@ -83,32 +85,45 @@ __global__ __launch_bounds__(256) void sample_head_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
   }
-  // logits: wave `wave` handles classes wave, wave+4, ...
-  for (int j = wave; j < n_class; j += 4) {
-    const float* wr = w + (int64_t)j * C;
-    float acc = 0.f;
+  // logits: NW waves, each takes 4 classes per iteration so that 8 independent
+  // 1-KiB weight-row loads are in flight per wave (the loop is latency bound).
+  constexpr int NW = SH_THREADS / 64;
+  for (int j0 = wave * 4; j0 < n_class; j0 += NW * 4) {
+    float acc[4];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + i * 256 + lane * 4);
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, n_class - 1);
+      const float* wr = w + (int64_t)j * C;
+      float a = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = fmaf(ww[e], v[i][e], acc);
+      for (int i = 0; i < VPL; ++i) {
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + i * 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = fmaf(ww[e], v[i][e], a);
+      }
+      acc[u] = a;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) lds[j] = acc * inv_temp;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float r = wave_sum(acc[u]);
+      if (lane == 0 && j0 + u < n_class) lds[j0 + u] = r * inv_temp;
+    }
   }
   __syncthreads();
   float* red = lds + n_class;
   float mx = -INFINITY;
-  for (int j = tid; j < n_class; j += 256) mx = fmaxf(mx, lds[j]);
+  for (int j = tid; j < n_class; j += SH_THREADS) mx = fmaxf(mx, lds[j]);
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  mx = red[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) mx = fmaxf(mx, red[k]);
   // argmax_j exp(l_j - max) / q_j  (first index wins ties)
   const float* er = expo + (int64_t)row * n_class;
   float best = -1.f;
   int best_j = 0x7fffffff;
-  for (int j = tid; j < n_class; j += 256) {
+  for (int j = tid; j < n_class; j += SH_THREADS) {
     const float sc = expf(lds[j] - mx) / er[j];
     if (sc > best) {
       best = sc;
@@ -125,14 +140,14 @@ __global__ __launch_bounds__(256) void sample_head_kernel(
     }
   }
   __syncthreads();
-  int* redj = reinterpret_cast<int*>(red + 4);
+  int* redj = reinterpret_cast<int*>(red + NW);
   if (lane == 0) {
     red[wave] = best;
     redj[wave] = best_j;
   }
   __syncthreads();
   if (tid == 0) {
-    for (int k = 1; k < 4; ++k)
+    for (int k = 1; k < NW; ++k)
       if (red[k] > best || (red[k] == best && redj[k] < best_j)) {
         best = red[k];
         best_j = redj[k];
@@ -178,8 +193,8 @@ extern "C" int t2h_sample_head(const float* hidden, const float* lnf_gamma, cons
               "t2h_sample_head: NULL pointer");
   T2H_REQUIRE(n > 0 && n_class > 0 && temp > 0.f, "t2h_sample_head: bad arguments");
   T2H_REQUIRE(C == 512, "t2h_sample_head: C=%d unsupported (512)", C);
-  const size_t lds = (size_t)(n_class + 8) * sizeof(float);
-  hipLaunchKernelGGL(sample_head_kernel<512>, dim3(n), dim3(256), lds,
+  const size_t lds = (size_t)(n_class + 2 * (SH_THREADS / 64)) * sizeof(float);
+  hipLaunchKernelGGL(sample_head_kernel<512>, dim3(n), dim3(SH_THREADS), lds,
                      static_cast<hipStream_t>(stream), hidden, lnf_gamma, lnf_beta, w_head, expo,
                      changes, tex, head, 1.0f / temp, x_t, out_idx, n_class);
   T2H_CHECK_LAUNCH("t2h_sample_head");

@@ -44,6 +44,59 @@ def _rows(t):
     return t.stride(0)
 
 
+GEMM_CFG_NAMES = ['64x64x32', '128x32x32', '128x64x32', '128x128x32', '128x64x64', '128x128x64',
+                  '128x64x32w8', '128x64x64w8', '128x128x64w8']
+
+
+def gemm_force_config(cfg):
+    return _lib.load().t2h_gemm_force_config(int(cfg))
+
+
+# ---- optional HIP-event profiling of GEMM launches (bench.py roofline leg) ----
+_prof = None
+
+
+def gemm_profile_start(every=1):
+    """Bracket every `every`-th t2h_gemm_f32 launch with HIP events on the
+    launch stream (torch's current stream)."""
+    global _prof
+    _prof = dict(every=max(1, int(every)), count=0, recs=[])
+
+
+def gemm_profile_stop():
+    """-> {kernel label: dict(kernel, n, ms, flops)} (synchronises)."""
+    global _prof
+    p, _prof = _prof, None
+    if not p:
+        return {}
+    torch.cuda.synchronize()
+    out = {}
+    for label, flops, e0, e1 in p['recs']:
+        r = out.setdefault(label, dict(kernel=label, n=0, ms=0.0, flops=0.0))
+        r['n'] += 1
+        r['ms'] += e0.elapsed_time(e1)
+        r['flops'] += flops
+    return out
+
+
+def _launch_gemm(g, what):
+    lib = _lib.load()
+    if _prof is not None:
+        _prof['count'] += 1
+        if _prof['count'] % _prof['every'] == 0:
+            cfg = lib.t2h_gemm_tile_config(ctypes.byref(g))
+            label = (f"gemm_kernel<{GEMM_CFG_NAMES[cfg]},amode={g.a_mode},"
+                     f"pro={int(bool(g.pro_scale))},btrans={g.b_trans}>")
+            flops = 2.0 * g.M * g.N * g.K * max(1, g.batch)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.t2h_gemm_f32(ctypes.byref(g), _stream()), what)
+            e1.record()
+            _prof['recs'].append((label, flops, e0, e1))
+            return
+    check(lib.t2h_gemm_f32(ctypes.byref(g), _stream()), what)
+
+
 def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=None,
          b_trans=False):
     """out[M,N] = act(alpha * pro(a)[M,K] @ w[N,K]^T + bias) + residual.
@@ -71,7 +124,7 @@ def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_rows, g.pro_ld, g.pro_act = rows, sc.shape[1], pact
     g.batch = 1
-    check(_lib.load().t2h_gemm_f32(ctypes.byref(g), _stream()), 't2h_gemm_f32')
+    _launch_gemm(g, 't2h_gemm_f32')
     return out
 
 
@@ -88,7 +141,7 @@ def bgemm(a, w, out, alpha=1.0, b_trans=False):
     g.lda, g.ldb, g.ldc = a.stride(1), w.stride(1), out.stride(1)
     g.strideA, g.strideB, g.strideC = a.stride(0), w.stride(0), out.stride(0)
     g.batch, g.alpha, g.b_trans = nb, alpha, int(b_trans)
-    check(_lib.load().t2h_gemm_f32(ctypes.byref(g), _stream()), 't2h_gemm_f32(batched)')
+    _launch_gemm(g, 't2h_gemm_f32(batched)')
     return out
 
 
@@ -127,7 +180,7 @@ def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=
         _chk_f32(sc, sh)
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_ld, g.pro_act = sc.shape[1], pact
-    check(_lib.load().t2h_gemm_f32(ctypes.byref(g), _stream()), 't2h_gemm_f32(conv)')
+    _launch_gemm(g, 't2h_gemm_f32(conv)')
     return out
 
 

@@ -1,0 +1,60 @@
+"""Batch sharding across the GPUs of one node.
+
+Images are independent units (GroupNorm/LayerNorm are per-sample, BN is in
+eval mode, attention never crosses samples), so the path shards with NO
+data-path collective: one process per GPU (torch.distributed over RCCL/xGMI),
+each rank owns the contiguous slice [lo, hi) of the global batch and a full
+weight replica (~0.9 GB fp32).  RCCL is used only for the barrier / max-time
+reduction of the benchmark and for the optional gather of finished uint8
+images to rank 0.
+"""
+import torch
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous split; the first (n_items % world) ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(data, rank, world):
+    """Slices every per-sample entry of a feed_data dict."""
+    n = len(data['img_name'])
+    lo, hi = shard_range(n, rank, world)
+    return {k: v[lo:hi] for k, v in data.items()}
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(value, world, device):
+    if world == 1:
+        return value
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def gather_images(u8, world, dst=0):
+    """Gathers per-rank uint8 image batches [b_r,H,W,3] on rank `dst` (ragged
+    shards allowed).  Returns the concatenated batch on dst, None elsewhere."""
+    if world == 1:
+        return u8
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    sizes = [torch.zeros(1, dtype=torch.int64, device=u8.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([u8.shape[0]], dtype=torch.int64, device=u8.device))
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    pad = torch.zeros((mx, ) + tuple(u8.shape[1:]), dtype=u8.dtype, device=u8.device)
+    pad[:u8.shape[0]] = u8
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
