@@ -2,8 +2,13 @@
 // style (no TxT matrix in HBM).  Replaces CausalSelfAttention.forward with
 // causal=False (models/archs/transformer_arch.py:52-67): softmax(q k^T/sqrt(64)) v.
 //
-// Workgroup = 4 waves = 128 query rows of one (batch, head); wave w owns 32
-// queries.  Keys/values stream through LDS in tiles of 64 keys.
+// Workgroup = 8 waves = 128 query rows of one (batch, head).  Wave w handles the
+// 32 queries (w & 3) against key half (w >> 2): the two waves that share a SIMD
+// work on different halves of the keys, so one wave's softmax VALU / LDS reads
+// run in the shadow of the other wave's MFMAs (at batch 8 the whole chip only
+// has 4 such 32-query units per CU, i.e. ONE wave per SIMD without the split).
+// The two partial results (running max m, running sum l, unnormalised O) are
+// merged through LDS at the end (flash-decoding style).
 //
 // Both matmuls are issued in TRANSPOSED form so that everything indexed by the
 // query stays lane-local (lane&31 = query, lane>>5 = k-half of the MFMA):
@@ -22,21 +27,23 @@ namespace {
 
 constexpr int HD = 64;       // head dim
 constexpr int QB = 128;      // queries per workgroup
-constexpr int KT = 64;       // keys per LDS tile
+constexpr int KT = 64;       // keys per LDS tile (per key half)
 constexpr int K_LD = 68;     // K tile row stride (17 x 16B slots, odd -> conflict-free b128)
 constexpr int V_LD = 64;
 constexpr int O_LD = 68;
+constexpr int KV_TILE = KT * K_LD + KT * V_LD;  // floats per (K,V) tile pair
 
-__global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
-                                                  float* __restrict__ y, int T, int C, int n_head) {
-  constexpr int SMEM_KV = KT * K_LD + KT * V_LD;
-  constexpr int SMEM_O = 4 * 32 * O_LD;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM_KV > SMEM_O ? SMEM_KV : SMEM_O];
-  float* const Ks = smem;
-  float* const Vs = smem + KT * K_LD;
+__global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
+                                                  float* __restrict__ y, int T, int C,
+                                                  int n_head) {
+  // [2 key halves][K tile | V tile]; reused at the end: [0, 8192) partial O of
+  // the second key half, [8192, 8192 + 4*32*O_LD) output transpose staging.
+  __shared__ __attribute__((aligned(16))) float smem[2 * KV_TILE];
+  static_assert(2 * KV_TILE >= 4 * 32 * 64 + 4 * 32 * O_LD, "LDS reuse layout");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
+  const int qw = wave & 3, kh = wave >> 2;
   // XCD-aware mapping (workgroup id % 8 = XCD): the T/128 query tiles of one
   // (batch, head) run on the same XCD and share its K/V through that L2.
   int qt, head, b;
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
     head = hb % n_head;
     b = hb / n_head;
   }
-  const int q0 = qt * QB + wave * 32;
+  const int q0 = qt * QB + qw * 32;
   const int ld = 3 * C;
   const float* base = qkv + (int64_t)b * T * ld + head * HD;
 
@@ -72,13 +79,18 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
     for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // staging: K/V tile = 64 keys x 64 floats = 1024 float4 each -> 4 + 4 per thread
-  const int s_col4 = tid & 15, s_row0 = tid >> 4;  // 16 float4 per key row, 16 rows per pass
+  // staging: per key half one K and one V tile of 64 keys x 64 floats = 1024
+  // float4 each; threads [0,256) stage half 0, [256,512) half 1: 4 + 4 per thread
+  const int s_half = tid >> 8, s_t = tid & 255;
+  const int s_col4 = s_t & 15, s_row0 = s_t >> 4;  // 16 float4 per key row, 16 rows per pass
+  float* const Ks_st = smem + s_half * KV_TILE;
+  float* const Vs_st = Ks_st + KT * K_LD;
+  const int half_keys = T / 2;
   f32x4 kreg[4], vreg[4];
-  auto load_kv = [&](int kt) {
+  auto load_kv = [&](int it) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int key = kt * KT + s_row0 + 16 * i;
+      const int key = s_half * half_keys + it * KT + s_row0 + 16 * i;
       const float* p = base + (int64_t)key * ld + s_col4 * 4;
       kreg[i] = *reinterpret_cast<const f32x4*>(p + C);
       vreg[i] = *reinterpret_cast<const f32x4*>(p + 2 * C);
@@ -88,18 +100,20 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = s_row0 + 16 * i;
-      *reinterpret_cast<f32x4*>(Ks + r * K_LD + s_col4 * 4) = kreg[i];
-      *reinterpret_cast<f32x4*>(Vs + r * V_LD + s_col4 * 4) = vreg[i];
+      *reinterpret_cast<f32x4*>(Ks_st + r * K_LD + s_col4 * 4) = kreg[i];
+      *reinterpret_cast<f32x4*>(Vs_st + r * V_LD + s_col4 * 4) = vreg[i];
     }
   };
 
-  const int nkt = T / KT;
+  const float* const Ks = smem + kh * KV_TILE;
+  const float* const Vs = Ks + KT * K_LD;
+  const int nit = half_keys / KT;
   load_kv(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // previous tile fully consumed
+  for (int it = 0; it < nit; ++it) {
+    __syncthreads();  // previous tiles fully consumed
     store_kv();
     __syncthreads();
-    if (kt + 1 < nkt) load_kv(kt + 1);
+    if (it + 1 < nit) load_kv(it + 1);
 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {  // two 32-key sub-tiles
@@ -121,11 +135,11 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = expf(m_run - m_new);  // first tile: exp(-inf) = 0
+      const float alpha = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);  // first tile: 0
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        st[r] = expf(st[r] - m_new);
+        st[r] = fast_exp(st[r] - m_new);
         psum += st[r];
       }
       psum += __shfl_xor(psum, 32, 64);
@@ -147,24 +161,53 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
     }
   }
 
-  // ---- normalise, transpose through LDS, coalesced row stores
+  // ---- merge the two key halves: waves 4-7 publish (m, l, O), waves 0-3 combine
   __syncthreads();
-  float* Os = smem + wave * 32 * O_LD;
-  const float inv_l = 1.0f / l_run;
+  float* const Ox = smem;                // [4 waves][32 regs][64 lanes]
+  float* const Mx = smem + 4 * 32 * 64;  // borrowed from the staging area below:
+  float* const Lx = Mx + 4 * 64;         // consumed before that area is written
+  if (kh == 1) {
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      Os[l31 * O_LD + d] = o_acc[dt][r] * inv_l;
+      for (int r = 0; r < 16; ++r) Ox[(qw * 32 + dt * 16 + r) * 64 + lane] = o_acc[dt][r];
+    Mx[qw * 64 + lane] = m_run;
+    Lx[qw * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  float inv_l = 0.f;
+  if (kh == 0) {
+    const float m2 = Mx[qw * 64 + lane], l2 = Lx[qw * 64 + lane];
+    const float m = fmaxf(m_run, m2);
+    const float a1 = expf(m_run - m), a2 = expf(m2 - m);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o_acc[dt][r] = o_acc[dt][r] * a1 + Ox[(qw * 32 + dt * 16 + r) * 64 + lane] * a2;
+    inv_l = 1.0f / (l_run * a1 + l2 * a2);
+  }
+  __syncthreads();  // Mx/Lx consumed before the staging area is overwritten
+  // ---- normalise, transpose through LDS, coalesced row stores (waves 0-3)
+  float* Os = smem + 4 * 32 * 64 + qw * 32 * O_LD;
+  if (kh == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        Os[l31 * O_LD + d] = o_acc[dt][r] * inv_l;
+      }
+  }
+  __syncthreads();
+  if (kh == 0) {
+    float* yb = y + ((int64_t)b * T + q0) * C + head * HD;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+      *reinterpret_cast<f32x4*>(yb + (int64_t)row * C + c4) =
+          *reinterpret_cast<const f32x4*>(Os + row * O_LD + c4);
     }
-  __syncthreads();
-  float* yb = y + ((int64_t)b * T + q0) * C + head * HD;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-    *reinterpret_cast<f32x4*>(yb + (int64_t)row * C + c4) =
-        *reinterpret_cast<const f32x4*>(Os + row * O_LD + c4);
   }
 }
 
@@ -177,7 +220,7 @@ extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int3
   T2H_REQUIRE(T > 0 && T % QB == 0, "t2h_mha_noncausal_f32: T=%d must be a multiple of %d", T, QB);
   T2H_REQUIRE(t2h_aligned16(qkv) && t2h_aligned16(y), "t2h_mha_noncausal_f32: 16-byte alignment");
   const int C = n_head * HD;
-  dim3 grid((T / QB) * n_head * B), block(256);
+  dim3 grid((T / QB) * n_head * B), block(512);
   hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv, y, T, C, n_head);
   T2H_CHECK_LAUNCH("t2h_mha_noncausal_f32");
   return T2H_OK;

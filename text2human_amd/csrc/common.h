@@ -48,3 +48,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// exp(x) as exp2(x*log2e) on v_exp_f32 with the rounding error of the product
+// (and of the log2e constant) folded back in: ~1-2 ulp like expf at 5 VALU ops
+// instead of ocml's ~20.  x must be finite or the caller handles -inf.
+__device__ __forceinline__ float fast_exp(float x) {
+  const float L = 1.44269502162933349609375f;    // float(log2 e)
+  const float Llo = 1.925963033500011e-8f;       // log2 e - L
+  const float t = x * L;
+  float e = fmaf(x, L, -t);
+  e = fmaf(x, Llo, e);
+  const float r = __builtin_amdgcn_exp2f(t);
+  return fmaf(r, e * 0.693147180559945309417f, r);
+}

@@ -24,6 +24,8 @@
 //     coordinate math and GroupNorm-apply + swish folded into the operand
 //     staging (per-(image,channel) scale/shift tables) -- zero padding is
 //     applied AFTER the activation, as the reference pads the activated tensor.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -39,7 +41,7 @@ __device__ __forceinline__ f32x4 prologue4(f32x4 v, const float* sc, const float
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float x = fmaf(v[e], s[e], t[e]);
-    if (act == 1) x = x / (1.0f + expf(-x));
+    if (act == 1) x = x / (1.0f + fast_exp(fminf(-x, 87.0f)));
     v[e] = x;
   }
   return v;
@@ -48,6 +50,19 @@ __device__ __forceinline__ f32x4 prologue4(f32x4 v, const float* sc, const float
 #ifdef T2H_GEMM_TIMING
 __device__ long long* g_timing_buf = nullptr;  // debug builds only (tools/gemm_timing.py)
 #endif
+
+// Inline-asm global load + counted wait: loads hipcc must NOT track, so that a
+// register piece can stay in flight across two K tiles and be waited for with an
+// exact `s_waitcnt vmcnt(N)` (hipcc only ever emits vmcnt(0) for loop-carried
+// loads).  The wait names the destination "+v" so the compiler cannot consume
+// the registers before the data has landed.
+__device__ __forceinline__ void gload4_async(f32x4& dst, const float* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt(f32x4& v) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
 
 // Register staging set of one K tile (global -> registers -> LDS).
 template <int A_F4, int B_F4>
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
       float x = v[e];
       if (PRO == 1) {
         x = fmaf(x, st.sc[e], st.sh[e]);
-        if (p.pro_act == 1) x = x / (1.0f + expf(-x));
+        if (p.pro_act == 1) x = x / (1.0f + fast_exp(fminf(-x, 87.0f)));
       }
       v[e] = ok ? x : 0.f;
     }
@@ -239,9 +254,146 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- prologue: tile 0 -> LDS[0]; tile 1 -> registers
   const int nk = p.K / BK;
   const int last = nk - 1;
+
+  // MFMA work of one K tile out of LDS[buf]; `aux(s)` is called after MFMA step s.
+  auto mma_tile = [&](int buf, auto&& aux) {
+    const float* Ab = As + buf * BM * LDS_LD + (wm0 + l31) * LDS_LD + (BK / 2) * hh;
+    const float* Bb = Bs + buf * BN * LDS_LD + (wn0 + l31) * LDS_LD + (BK / 2) * hh;
+    f32x4 af[2][TM], bf[2][TN];  // MFMA operand fragments, double-buffered over j
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) af[0][ti] = *reinterpret_cast<const f32x4*>(Ab + ti * 32 * LDS_LD);
+#pragma unroll
+    for (int tj = 0; tj < TN; ++tj) bf[0][tj] = *reinterpret_cast<const f32x4*>(Bb + tj * 32 * LDS_LD);
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+      if (j + 1 < BK / 8) {  // next group's fragments fly under this group's MFMAs
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+          af[(j + 1) & 1][ti] = *reinterpret_cast<const f32x4*>(Ab + ti * 32 * LDS_LD + 4 * (j + 1));
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj)
+          bf[(j + 1) & 1][tj] = *reinterpret_cast<const f32x4*>(Bb + tj * 32 * LDS_LD + 4 * (j + 1));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TN; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][ti][e], bf[j & 1][tj][e],
+                                                                acc[ti][tj], 0, 0, 0);
+        aux(4 * j + e);
+      }
+    }
+  };
+
+  constexpr bool DEEP = (AMODE == 0 && PRO == 0 && !BTRANS);
+  if constexpr (DEEP) {
+    // ---- plain GEMM: TWO register sets, every global load flies for two K tiles.
+    // Slot q (B pieces, then A pieces) of the set holding tile kt+1 is waited for
+    // with an exact vmcnt (all 2L-1 younger loads may still be in flight), written
+    // to LDS[(kt+1)&1] and immediately re-issued for tile kt+3.
+    constexpr int L = A_F4 + B_F4;
+    constexpr int STEPS = BK / 2;
+    f32x4 ra[2][A_F4], rb[2][B_F4];
+    const float* a_src[A_F4];
+    const float* b_src[B_F4];
+    unsigned a_ok = 0u;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const bool ok = a_off[i] >= 0;
+      a_src[i] = Ag + (ok ? a_off[i] : (int64_t)(col4 * 4));
+      if (ok) a_ok |= 1u << i;
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const bool ok = (b_ok >> i) & 1u;
+      b_src[i] = Bg + (int64_t)(ok ? n0 + row0 + RPP * i : 0) * p.ldb + col4 * 4;
+    }
+    auto put_a = [&](int i, const f32x4& r, int buf) {
+      f32x4 v = r;
+      const bool ok = (a_ok >> i) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+      *reinterpret_cast<f32x4*>(As + buf * BM * LDS_LD + (row0 + RPP * i) * LDS_LD + col4 * 4) = v;
+    };
+    auto put_b = [&](int i, const f32x4& r, int buf) {
+      f32x4 v = r;
+      const bool ok = (b_ok >> i) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+      *reinterpret_cast<f32x4*>(Bs + buf * BN * LDS_LD + (row0 + RPP * i) * LDS_LD + col4 * 4) = v;
+    };
+    auto issue = [&](auto setc, int kt) {  // all loads of tile kt into register set S
+      constexpr int S = decltype(setc)::value;
+      const int k0 = min(kt, last) * BK;
+#pragma unroll
+      for (int i = 0; i < B_F4; ++i) gload4_async(rb[S][i], b_src[i] + k0);
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) gload4_async(ra[S][i], a_src[i] + k0);
+    };
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    issue(set0{}, 0);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      wait_vmcnt<0>(rb[0][i]);
+      put_b(i, rb[0][i], 0);
+    }
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      wait_vmcnt<0>(ra[0][i]);
+      put_a(i, ra[0][i], 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue(set1{}, 1);
+    issue(set0{}, 2);
+    __syncthreads();
+
+    auto step = [&](int kt, auto setc) {  // set S holds tile kt+1
+      constexpr int S = decltype(setc)::value;
+      const int buf = kt & 1;
+      const int kn = min(kt + 3, last) * BK;
+      mma_tile(buf, [&](int s) {
+#pragma unroll
+        for (int q = 0; q < L; ++q) {
+          const int at = (L <= STEPS) ? STEPS - L + q : (q * STEPS) / L;
+          if (at != s) continue;
+          __builtin_amdgcn_sched_barrier(0);
+          if (q < B_F4) {
+            wait_vmcnt<2 * L - 1>(rb[S][q]);
+            put_b(q, rb[S][q], buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gload4_async(rb[S][q], b_src[q] + kn);
+          } else {
+            wait_vmcnt<2 * L - 1>(ra[S][q - B_F4]);
+            put_a(q - B_F4, ra[S][q - B_F4], buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gload4_async(ra[S][q - B_F4], a_src[q - B_F4] + kn);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      step(kt, set1{});
+      step(kt + 1, set0{});
+    }
+    if (nk & 1) step(nk - 1, set1{});
+    // drain the clamped tail loads before the registers can be reused
+#pragma unroll
+    for (int S = 0; S < 2; ++S) {
+#pragma unroll
+      for (int i = 0; i < B_F4; ++i) wait_vmcnt<0>(rb[S][i]);
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) wait_vmcnt<0>(ra[S][i]);
+    }
+  } else {
+  // ---- prologue: tile 0 -> LDS[0]; tile 1 -> registers
   {
     const TileK t0 = tile_k(0);
     load_tbl(t0);
@@ -279,33 +431,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const TileK tn = tile_k(min(kt + 2, last));
-    const float* Ab = As + buf * BM * LDS_LD + (wm0 + l31) * LDS_LD + (BK / 2) * hh;
-    const float* Bb = Bs + buf * BN * LDS_LD + (wn0 + l31) * LDS_LD + (BK / 2) * hh;
-    f32x4 af[2][TM], bf[2][TN];  // MFMA operand fragments, double-buffered over j
-#pragma unroll
-    for (int ti = 0; ti < TM; ++ti) af[0][ti] = *reinterpret_cast<const f32x4*>(Ab + ti * 32 * LDS_LD);
-#pragma unroll
-    for (int tj = 0; tj < TN; ++tj) bf[0][tj] = *reinterpret_cast<const f32x4*>(Bb + tj * 32 * LDS_LD);
-#pragma unroll
-    for (int j = 0; j < BK / 8; ++j) {
-      if (j + 1 < BK / 8) {  // next group's fragments fly under this group's MFMAs
-#pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
-          af[(j + 1) & 1][ti] = *reinterpret_cast<const f32x4*>(Ab + ti * 32 * LDS_LD + 4 * (j + 1));
-#pragma unroll
-        for (int tj = 0; tj < TN; ++tj)
-          bf[(j + 1) & 1][tj] = *reinterpret_cast<const f32x4*>(Bb + tj * 32 * LDS_LD + 4 * (j + 1));
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
-#pragma unroll
-          for (int tj = 0; tj < TN; ++tj)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][ti][e], bf[j & 1][tj][e],
-                                                                acc[ti][tj], 0, 0, 0);
+    mma_tile(buf, [&](int s) {
         // auxiliary pieces pinned after MFMA step s: stores first, then loads
-        const int s = 4 * j + e;
 #pragma unroll
         for (int q = 0; q < 2 * NPIECE; ++q) {
           const int at = (2 * NPIECE <= STEPS) ? FIRST + q : (q * STEPS) / (2 * NPIECE);
@@ -333,8 +460,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
 #endif
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
-    }
+    });
 #ifdef T2H_GEMM_TIMING
     const long long tb0 = clock64();
 #endif
@@ -349,6 +475,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
     g_timing_buf[3] = tm_bar; g_timing_buf[4] = clock64() - tm_begin; g_timing_buf[5] = nk;
   }
 #endif
+  }  // !DEEP
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31,
   //      row = (r&3) + 8*(r>>2) + 4*(lane>>5)
