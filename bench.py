@@ -100,6 +100,29 @@ def cpu_baseline(sample_steps, n_sub):
                     sample='worker exceeded its 240 s time box')
 
 
+def pmc_traffic(kernel_label):
+    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be
+    read from inside the benchmark; they come from the separate rocprofv3 --pmc
+    passes of this same bench command committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE in their own passes, gfx950 FETCH x2 correction, see
+    tools/pmc_summary.py) -- launch-weighted over the kernel's shapes."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
+    m = __import__('re').match(r'gemm_kernel<(\d+)x(\d+)x(\d+)(w8)?,amode=(\d),pro=(\d),btrans=(\d)>', kernel_label)
+    if not (os.path.exists(path) and m):
+        return {'traffic': None}
+    bm, bn, bk, w8, am, pro, bt = m.groups()
+    wm, wn = ('4', '2') if w8 else (('4', '1') if bn == '32' else ('2', '2'))
+    name = f'gemm_kernel<{bm}, {bn}, {bk}, {wm}, {wn}, {am}, {pro}, {"true" if bt == "1" else "false"}>'
+    rows = [r for r in json.load(open(path)) if r['kernel'] == name]
+    if not rows:
+        return {'traffic': None}
+    n = sum(r['launches'] for r in rows)
+    mb = sum(r['traffic_mb'] * r['launches'] for r in rows) / n
+    util = sum(r['mfma_util'] * r['launches'] for r in rows) / n
+    return {'traffic': mb * 1e6, 'traffic_unit': 'bytes/launch', 'mfma_util_pmc': util,
+            'traffic_source': 'profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'}
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_worker:
@@ -190,6 +213,7 @@ def main():
             'all_gemm_kernels': {k: {'TFLOP/s': v['flops'] / (v['ms'] * 1e-3) / 1e12, 'n': v['n'],
                                      'avg_us': 1000.0 * v['ms'] / v['n']} for k, v in prof.items()},
         }
+        out['roofline'].update(pmc_traffic(dom['kernel']))
     # whole-path arithmetic rate against the same peak (26.17 TFLOP / image)
     out['path_tflops'] = 26.17 * out['value'] / world
     if world == 1 and not args.no_cpu_baseline:

@@ -188,6 +188,19 @@ int t2h_argmax_rows_f32(const float* x, int32_t ld, int64_t* out, int64_t rows,
  * mul(255).add(0.5).clamp(0,255) (models/sample_model.py:245-254) */
 int t2h_image_epilogue(const float* dec, int32_t ldd, float* img_nchw, uint8_t* img_u8,
                        int32_t B, int32_t HW, void* stream);
+/* ShapeAttrEmbedding.forward (models/archs/shape_attr_embedding_arch.py:23-35).
+ * w0t: first-layer weights transposed and stacked [sum(cls_num), dim] with
+ * cls_off[a] = first row of attribute a; b0 [n_attr,dim]; w1 [n_attr,dim,dim];
+ * b1 [n_attr,dim]; f0 [out_dim, n_attr*dim]; f1 [out_dim,out_dim]. */
+int t2h_shape_attr_embed_f32(const int64_t* attr, const int32_t* cls_off, const float* w0t,
+                             const float* b0, const float* w1, const float* b1, const float* f0,
+                             const float* fb0, const float* f1, const float* fb1, float* out,
+                             int32_t B, int32_t n_attr, int32_t dim, int32_t out_dim, void* stream);
+/* per-pixel bias map of the spatially constant attribute channels that ShapeUNet
+ * concatenates in front of every encoder stage (unet_arch.py:660-667):
+ * out[b,y,x,co] = sum of tapc[b,co,tap] over the 3x3 taps that fall inside the image */
+int t2h_tap_bias_map_f32(const float* tapc, float* out, int32_t B, int32_t H, int32_t W,
+                         int32_t Cout, void* stream);
 /* generate_texture_map rule (models/sample_model.py:443-467) */
 int t2h_texture_map(const int64_t* segm, const int64_t* upper, const int64_t* lower,
                     const int64_t* outer, float* mask, int32_t B, int32_t HW,

@@ -64,6 +64,8 @@ SIGNATURES = {
     't2h_bilinear_up2_nhwc_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     't2h_argmax_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i32, c_vp]),
     't2h_image_epilogue': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    't2h_shape_attr_embed_f32': (ctypes.c_int, [c_vp] * 11 + [c_i32] * 4 + [c_vp]),
+    't2h_tap_bias_map_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     't2h_texture_map': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
 }
 

@@ -236,3 +236,97 @@ extern "C" int t2h_texture_map(const int64_t* segm, const int64_t* upper, const 
   T2H_CHECK_LAUNCH("t2h_texture_map");
   return T2H_OK;
 }
+
+// ---------------------------------------------------------------- pose front-end glue
+namespace {
+
+// ShapeAttrEmbedding.forward (shape_attr_embedding_arch.py:23-35): per attribute
+// one-hot -> Linear(cls,8) -> LeakyReLU(0.01) -> Linear(8,8); concat -> Linear(120,128)
+// -> LeakyReLU -> Linear(128,128).  One workgroup (128 threads) per sample; the
+// one-hot Linear is a row lookup in the transposed first-layer weights.
+__global__ __launch_bounds__(128) void shape_attr_embed_kernel(
+    const int64_t* __restrict__ attr, const int* __restrict__ cls_off, const float* __restrict__ w0t,
+    const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ f0, const float* __restrict__ fb0, const float* __restrict__ f1,
+    const float* __restrict__ fb1, float* __restrict__ out, int n_attr, int dim, int out_dim) {
+  __shared__ float h0[256], h1[256], h2[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int cat = n_attr * dim;
+  if (t < cat) {
+    const int a = t / dim, j = t - a * dim;
+    const int row = cls_off[a] + (int)attr[(int64_t)b * n_attr + a];
+    const float v = w0t[(int64_t)row * dim + j] + b0[a * dim + j];
+    h0[t] = v >= 0.f ? v : 0.01f * v;
+  }
+  __syncthreads();
+  if (t < cat) {
+    const int a = t / dim, j = t - a * dim;
+    float acc = b1[a * dim + j];
+    for (int k = 0; k < dim; ++k) acc = fmaf(w1[(a * dim + j) * dim + k], h0[a * dim + k], acc);
+    h1[t] = acc;
+  }
+  __syncthreads();
+  for (int o = t; o < out_dim; o += blockDim.x) {
+    float acc = fb0[o];
+    for (int k = 0; k < cat; ++k) acc = fmaf(f0[(int64_t)o * cat + k], h1[k], acc);
+    h2[o] = acc >= 0.f ? acc : 0.01f * acc;
+  }
+  __syncthreads();
+  for (int o = t; o < out_dim; o += blockDim.x) {
+    float acc = fb1[o];
+    for (int k = 0; k < out_dim; ++k) acc = fmaf(f1[(int64_t)o * out_dim + k], h2[k], acc);
+    out[(int64_t)b * out_dim + o] = acc;
+  }
+}
+
+// Per-pixel bias of spatially constant input channels of a 3x3 pad-1 conv:
+// out[b, y, x, co] = sum over taps (dy,dx) whose source pixel lies inside the image
+// of tapc[b, co, tap]  (the zero padding removes the taps that fall outside).
+__global__ void tap_bias_map_kernel(const float* __restrict__ tapc, float* __restrict__ out, int H,
+                                    int W, int Cout, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*H*W*Cout
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  int64_t p = i / Cout;
+  const int x = (int)(p % W);
+  p /= W;
+  const int y = (int)(p % H);
+  const int b = (int)(p / H);
+  const float* t = tapc + ((int64_t)b * Cout + co) * 9;
+  float acc = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int sy = y + dy - 1, sx = x + dx - 1;
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W) acc += t[dy * 3 + dx];
+    }
+  out[i] = acc;
+}
+
+}  // namespace
+
+extern "C" int t2h_shape_attr_embed_f32(const int64_t* attr, const int32_t* cls_off, const float* w0t,
+                                        const float* b0, const float* w1, const float* b1,
+                                        const float* f0, const float* fb0, const float* f1,
+                                        const float* fb1, float* out, int32_t B, int32_t n_attr,
+                                        int32_t dim, int32_t out_dim, void* stream) {
+  T2H_REQUIRE(attr && cls_off && w0t && b0 && w1 && b1 && f0 && fb0 && f1 && fb1 && out,
+              "t2h_shape_attr_embed_f32: NULL pointer");
+  T2H_REQUIRE(B > 0 && n_attr > 0 && dim > 0 && n_attr * dim <= 128 && out_dim > 0 && out_dim <= 256,
+              "t2h_shape_attr_embed_f32: unsupported sizes");
+  hipLaunchKernelGGL(shape_attr_embed_kernel, dim3(B), dim3(128), 0, static_cast<hipStream_t>(stream),
+                     attr, cls_off, w0t, b0, w1, b1, f0, fb0, f1, fb1, out, n_attr, dim, out_dim);
+  T2H_CHECK_LAUNCH("t2h_shape_attr_embed_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_tap_bias_map_f32(const float* tapc, float* out, int32_t B, int32_t H, int32_t W,
+                                    int32_t Cout, void* stream) {
+  T2H_REQUIRE(tapc && out && B > 0 && H > 0 && W > 0 && Cout > 0, "t2h_tap_bias_map_f32: bad arguments");
+  const int64_t total = (int64_t)B * H * W * Cout;
+  hipLaunchKernelGGL(tap_bias_map_kernel, grid1d(total), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     tapc, out, H, W, Cout, total);
+  T2H_CHECK_LAUNCH("t2h_tap_bias_map_f32");
+  return T2H_OK;
+}

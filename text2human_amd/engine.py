@@ -247,17 +247,8 @@ class UNetStack:
         P = self.P
         wattr = P[f'{pfx}.wattr']  # [Cout, 9, A]
         cout = wattr.shape[0]
-        tapc = ops.gemm(attr, wattr.view(cout * 9, -1)).view(n_img, cout, 9)  # [B, Cout, 9]
-        dev = attr.device
-        ys, xs = torch.arange(h, device=dev), torch.arange(w, device=dev)
-        valid = torch.zeros((9, h, w), device=dev, dtype=torch.float32)
-        for dy in range(3):
-            for dx in range(3):
-                vy = ((ys + dy - 1) >= 0) & ((ys + dy - 1) < h)
-                vx = ((xs + dx - 1) >= 0) & ((xs + dx - 1) < w)
-                valid[dy * 3 + dx] = (vy[:, None] & vx[None, :]).float()
-        # 9 validity patterns only; plain PyTorch glue on a [B,Cout,9]x[9,HW] product
-        return torch.einsum('bct,tp->bpc', tapc, valid.view(9, h * w)).reshape(n_img * h * w, cout).contiguous()
+        tapc = ops.gemm(attr, wattr.view(cout * 9, -1))  # [B, Cout*9] = [B, Cout, 9]
+        return ops.tap_bias_map(tapc, n_img, h, w, cout)
 
     def forward(self, x, n_img, h, w, attr=None):
         nm = self.name

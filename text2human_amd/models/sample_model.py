@@ -245,19 +245,8 @@ class SampleFromPoseModel(BaseSampleModel):
             self.sample_and_refine(save_dir, img_name)
 
     def _attr_embedding(self, shape_attr):
-        """ShapeAttrEmbedding.forward (shape_attr_embedding_arch.py:23-35):
-        one-hot -> Linear == column gather of the first Linear's weight."""
-        P = self.P
-        parts = []
-        for i, _ in enumerate(self.shape_emb['cls_num']):
-            w0, b0 = P[f'semb.attr_{i}.0.weight'], P[f'semb.attr_{i}.0.bias']
-            x = w0.t()[shape_attr[:, i]] + b0          # [B, 8] (index plumbing)
-            x = torch.where(x >= 0, x, x * 0.01)      # LeakyReLU(0.01)
-            parts.append(x @ P[f'semb.attr_{i}.2.weight'].t() + P[f'semb.attr_{i}.2.bias'])
-        x = torch.cat(parts, 1)
-        x = x @ P['semb.fusion.0.weight'].t() + P['semb.fusion.0.bias']
-        x = torch.where(x >= 0, x, x * 0.01)
-        return (x @ P['semb.fusion.2.weight'].t() + P['semb.fusion.2.bias']).contiguous()
+        """ShapeAttrEmbedding.forward (shape_attr_embedding_arch.py:23-35)."""
+        return ops.shape_attr_embed(shape_attr.long().contiguous(), self.shape_emb)
 
     @torch.no_grad()
     def generate_parsing_map(self):

@@ -385,3 +385,25 @@ def texture_map(segm, upper, lower, outer):
     check(_lib.load().t2h_texture_map(_p(segm), _p(upper), _p(lower), _p(outer), _p(mask), B, hw,
                                       _stream()), 't2h_texture_map')
     return mask
+
+
+def shape_attr_embed(attr, emb):
+    """attr i64 [B, n_attr]; emb = dict of packed tensors (weights.pack_shape_embedder)."""
+    _chk_i64(attr)
+    B, n_attr = attr.shape
+    out = torch.empty((B, emb['out_dim']), device=attr.device, dtype=torch.float32)
+    check(_lib.load().t2h_shape_attr_embed_f32(
+        _p(attr), _p(emb['cls_off']), _p(emb['w0t']), _p(emb['b0']), _p(emb['w1']), _p(emb['b1']),
+        _p(emb['f0']), _p(emb['fb0']), _p(emb['f1']), _p(emb['fb1']), _p(out), B, n_attr, emb['dim'],
+        emb['out_dim'], _stream()), 't2h_shape_attr_embed_f32')
+    return out
+
+
+def tap_bias_map(tapc, B, H, W, cout):
+    """tapc f32 [B, cout, 9] -> rows [B*H*W, cout]."""
+    _chk_f32(tapc)
+    assert tapc.is_contiguous()
+    out = torch.empty((B * H * W, cout), device=tapc.device, dtype=torch.float32)
+    check(_lib.load().t2h_tap_bias_map_f32(_p(tapc), _p(out), B, H, W, cout, _stream()),
+          't2h_tap_bias_map_f32')
+    return out

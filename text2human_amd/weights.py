@@ -234,9 +234,27 @@ def pack_fcn_head(P, sd, dst):
 
 
 def pack_shape_embedder(P, sd, dst, cls_num_list):
-    for k, v in sd.items():
-        P.put(f'{dst}.{k}', v)
-    return dict(cls_num=list(cls_num_list))
+    """ShapeAttrEmbedding -> tensors of t2h_shape_attr_embed_f32."""
+    n = len(cls_num_list)
+    dim = sd['attr_0.2.weight'].shape[0]
+    out_dim = sd['fusion.2.weight'].shape[0]
+    offs, acc = [], 0
+    for c in cls_num_list:
+        offs.append(acc)
+        acc += c
+    P.put(f'{dst}.w0t', torch.cat([sd[f'attr_{i}.0.weight'].t() for i in range(n)], 0))
+    P.put(f'{dst}.b0', torch.stack([sd[f'attr_{i}.0.bias'] for i in range(n)], 0))
+    P.put(f'{dst}.w1', torch.stack([sd[f'attr_{i}.2.weight'] for i in range(n)], 0))
+    P.put(f'{dst}.b1', torch.stack([sd[f'attr_{i}.2.bias'] for i in range(n)], 0))
+    P.put(f'{dst}.f0', sd['fusion.0.weight'])
+    P.put(f'{dst}.fb0', sd['fusion.0.bias'])
+    P.put(f'{dst}.f1', sd['fusion.2.weight'])
+    P.put(f'{dst}.fb1', sd['fusion.2.bias'])
+    cls_off = torch.tensor(offs, dtype=torch.int32, device=P.device)
+    emb = dict(cls_off=cls_off, dim=dim, out_dim=out_dim, cls_num=list(cls_num_list))
+    for k in ('w0t', 'b0', 'w1', 'b1', 'f0', 'fb0', 'f1', 'fb1'):
+        emb[k] = P[f'{dst}.{k}']
+    return emb
 
 
 def stack_codebooks(sd):
