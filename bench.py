@@ -135,10 +135,23 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU path exists)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("T2H_FORCE_DIST") == "1"  # test hook: RCCL init with 1 rank
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        # RCCL prints a version banner on stdout at communicator creation; stdout is
+        # reserved for the ONE JSON line, so route fd 1 to stderr while RCCL comes up.
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from text2human_amd import defaults, ops, options, shard, synthetic
     from text2human_amd.models import SampleFromParsingModel
@@ -163,15 +176,15 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    shard.barrier(world)
+    shard.barrier(2 if use_dist else 1)
     torch.cuda.synchronize()
     ops.gemm_profile_start(every=37)  # HIP-event pairs around a sample of GEMM launches
     t0 = time.perf_counter()
     for _ in range(args.steps):
         u8 = one_step()
     torch.cuda.synchronize()
-    shard.barrier(world)
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, world, dev)
+    shard.barrier(2 if use_dist else 1)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, 2 if use_dist else 1, dev)
     prof = ops.gemm_profile_stop()
     assert u8.shape == (hi - lo, 512, 256, 3)
 
@@ -219,7 +232,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.sample_steps, args.cpu_sampler_steps)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

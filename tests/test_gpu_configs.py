@@ -1,0 +1,91 @@
+"""Parity (-m gpu) on the BASELINE.json configurations that are not the bench
+line: configs[2] sample_from_pose end to end, configs[4] the 1024x512 upscaled
+hierarchy (SURVEY.md 8(d) interpretation: nearest-x2 of both quantised latents,
+then the fully convolutional decoders)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_ref as R
+from text2human_amd import defaults, options, synthetic
+from text2human_amd.models import SampleFromPoseModel
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def opt():
+    return options.dict_to_nonedict(defaults.sample_from_pose())
+
+
+@pytest.fixture(scope='module')
+def sds(opt):
+    return synthetic.make_state_dicts(opt, seed=4321)
+
+
+@pytest.fixture(scope='module')
+def model(opt, sds):
+    return SampleFromPoseModel(opt, state_dicts=sds)
+
+
+def test_sample_from_pose_end_to_end(model, sds, opt):
+    """densepose + attributes -> parsing -> tokens -> 2 sampling steps -> image,
+    stage by stage against the oracle (the oracle's parsing map is injected after
+    the parsing stage so that a near-tie argmax cannot cascade)."""
+    pb = synthetic.pose_batch(2, seed=8)
+    model.feed_data(pb)
+    model.generate_parsing_map()
+    with torch.no_grad():
+        segm_ref, logits = R.parsing_from_pose(pb['densepose'], pb['shape_attr'], sds['shape_embedder'],
+                                               sds['shape_encoder'], sds['shape_decoder'],
+                                               opt['shape_attr_class_num'])
+    bad = model.segm.cpu() != segm_ref
+    t2 = logits.topk(2, dim=1).values
+    margin = (t2[:, 0] - t2[:, 1]).unsqueeze(1)
+    assert (margin[bad] < 1e-4).all(), f'{int(bad.sum())} parsing pixels differ beyond a near-tie'
+    assert bad.float().mean() < 1e-3
+    model.segm = segm_ref.to(DEV)                      # identical upstream for the next stages
+    model.generate_quantized_segm()
+    model.generate_texture_map()
+    with torch.no_grad():
+        tok_ref = R.segm_tokens(segm_ref, sds['segm_encoder'], sds['segm_quant_conv'],
+                                sds['segm_quantizer']['embedding.weight']).view(2, -1)
+        mask_ref = R.texture_map(segm_ref, pb['upper_fused_attr'], pb['lower_fused_attr'],
+                                 pb['outer_fused_attr'])
+    assert torch.equal(model.segm_tokens.cpu(), tok_ref)
+    assert torch.equal(model.texture_mask.cpu(), mask_ref)
+    model.noise = R.SeededNoise(17, 'cpu')
+    try:
+        top = model.sample_fn(temp=1, sample_steps=2)
+    finally:
+        model.noise = None
+    with torch.no_grad():
+        top_ref = R.sample_fn(tok_ref, mask_ref, sds['sampler'], 2, noise=R.SeededNoise(17, 'cpu'))
+        img_ref, _ = R.refine_and_decode(top_ref, mask_ref, sds)
+    assert torch.equal(torch.stack(top).cpu(), torch.stack(top_ref))
+    img, _ = model.decode_indices(top)
+    assert (img.cpu() - img_ref).abs().max().item() < 2e-4
+
+
+def test_upscaled_hierarchy_1024x512(model, sds):
+    g = torch.Generator().manual_seed(31)
+    tex = torch.randint(0, 18, (1, 512), generator=g)
+    val = torch.randint(0, 1024, (1, 512), generator=g)
+    top = [torch.where(tex == h, val, torch.full_like(val, -1)) for h in range(18)]
+    mask = tex.view(1, 1, 32, 16).float().repeat_interleave(16, 2).repeat_interleave(16, 3)
+    model.texture_mask, model.batch_size = mask.to(DEV), 1
+    img, _, inter = model.decode_indices([t.to(DEV) for t in top], return_inter=True, upscale=True)
+    assert img.shape == (1, 3, 1024, 512)
+    with torch.no_grad():
+        pq, bq = sds['top_post_quant_conv'], sds['bot_post_quant_conv']
+        tq = F.conv2d(R.top_codebook_entry(top, mask, sds['top_quantize']), pq['weight'], pq['bias'])
+        bot_idx = R.bot_index_prediction(tq, mask, sds['guidance_encoder'], sds['index_decoder'])
+        qb = F.conv2d(R.bot_codebook_entry(bot_idx, mask, sds['bot_quantize']), bq['weight'], bq['bias'])
+        up = lambda t: F.interpolate(t, scale_factor=2.0, mode='nearest')
+        bh = R.decoder_res(up(qb), sds['bot_decoder_res'])
+        dec = R.decoder(up(tq), sds['decoder'], bot_h=bh)
+        ref = ((dec + 1) / 2).clamp(0, 1)
+    got_bot = inter[0]['bot_lists'].view(18, 1, 32, 16).cpu()
+    assert torch.equal(got_bot, torch.stack(bot_idx))
+    assert (img.cpu() - ref).abs().max().item() < 2e-4

@@ -1,0 +1,121 @@
+"""Edge cases of the HIP path (-m gpu): odd batch sizes, decode chunk
+boundaries, non-default resolutions (the decoder is fully convolutional),
+degenerate schedules and argument validation."""
+import pytest
+import torch
+
+from oracle import torch_ref as R
+from text2human_amd import defaults, ops, options, synthetic
+from text2human_amd._lib import T2HError
+from text2human_amd.models import SampleFromParsingModel
+from text2human_amd.models import sample_model as sm
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def opt():
+    return options.dict_to_nonedict(defaults.sample_from_parsing())
+
+
+@pytest.fixture(scope='module')
+def sds(opt):
+    return synthetic.make_state_dicts(opt, seed=77)
+
+
+@pytest.fixture(scope='module')
+def model(opt, sds):
+    return SampleFromParsingModel(opt, state_dicts=sds)
+
+
+def _rand_indices(b, seed):
+    g = torch.Generator().manual_seed(seed)
+    tex = torch.randint(0, 18, (b, 512), generator=g)
+    top = torch.full((18, b, 512), -1, dtype=torch.int64)
+    val = torch.randint(0, 1024, (b, 512), generator=g)
+    for h in range(18):
+        top[h][tex == h] = val[tex == h]
+    mask = tex.view(b, 1, 32, 16).float().repeat_interleave(16, 2).repeat_interleave(16, 3)
+    return top, mask
+
+
+def test_batch_of_one_matches_oracle(model, sds):
+    batch = synthetic.parsing_batch(1, seed=5)
+    model.feed_data(batch)
+    model.noise = R.SeededNoise(3, 'cpu')
+    try:
+        top = model.sample_fn(temp=1, sample_steps=2)
+    finally:
+        model.noise = None
+    with torch.no_grad():
+        tok = R.segm_tokens(batch['segm'], sds['segm_encoder'], sds['segm_quant_conv'],
+                            sds['segm_quantizer']['embedding.weight']).view(1, -1)
+        ref = R.sample_fn(tok, batch['texture_mask'], sds['sampler'], 2, noise=R.SeededNoise(3, 'cpu'))
+    assert torch.equal(model.segm_tokens.cpu(), tok)
+    assert torch.equal(torch.stack(top).cpu(), torch.stack(ref))
+
+
+def test_decode_chunk_boundary_is_invisible(model):
+    """B = 3 with a chunk size of 2: chunked batched decode == per-image decode."""
+    top, mask = _rand_indices(3, seed=9)
+    model.texture_mask, model.batch_size = mask.to(DEV), 3
+    old = sm.DECODE_CHUNK
+    try:
+        sm.DECODE_CHUNK = 2
+        img, u8 = model.decode_indices([t.to(DEV) for t in top], want_u8=True)
+    finally:
+        sm.DECODE_CHUNK = old
+    assert img.shape == (3, 3, 512, 256) and u8.shape == (3, 512, 256, 3)
+    for i in range(3):
+        model.texture_mask, model.batch_size = mask[i:i + 1].to(DEV), 1
+        one, _ = model.decode_indices([t[i:i + 1].to(DEV) for t in top])
+        assert torch.equal(one[0], img[i]), f'image {i} depends on its batch neighbours'
+
+
+def test_decoder_is_resolution_agnostic(model, sds):
+    """16x8 latents (256x128 image): same kernels, oracle is the same functional decoder."""
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(2, 256, 16, 8, generator=g) * 0.05
+    zb = torch.randn(2, 256, 32, 16, generator=g) * 0.05
+    with torch.no_grad():
+        bh = R.decoder_res(zb, sds['bot_decoder_res'])
+        ref = R.decoder(z, sds['decoder'], bot_h=bh)
+    bot_h = model.bot_decoder_res.decode_res(ops.nchw_to_nhwc(zb.to(DEV)), 2, 32, 16)
+    dec, ho, wo = model.decoder.decode(ops.nchw_to_nhwc(z.to(DEV)), 2, 16, 8, bot_h=bot_h)
+    assert (ho, wo) == (256, 128)
+    got = ops.nhwc_to_nchw(dec, 2, 256, 128).cpu()
+    assert (got - ref).abs().max().item() < 2e-4
+
+
+def test_single_step_schedule_unmasks_everything(model):
+    """sample_steps = 1: t = 1 -> rand < 1 is always true, every token is drawn once."""
+    batch = synthetic.parsing_batch(2, seed=21)
+    model.feed_data(batch)
+    top = torch.stack(model.sample_fn(temp=1, sample_steps=1))
+    tex = model._texture_tokens(model.texture_mask)
+    chosen = top.gather(0, tex.unsqueeze(0)).squeeze(0)
+    assert (chosen >= 0).all() and (chosen < 1024).all()
+    assert ((top >= 0).sum(0) == 1).all()          # exactly one head owns each token
+
+
+def test_all_background_mask_uses_head_zero_only(model):
+    batch = synthetic.parsing_batch(2, seed=22)
+    batch['texture_mask'] = torch.zeros_like(batch['texture_mask'])
+    model.feed_data(batch)
+    top = torch.stack(model.sample_fn(temp=1, sample_steps=3))
+    assert (top[0] >= 0).all() and (top[1:] == -1).all()
+
+
+def test_argument_validation_raises():
+    a = torch.zeros(64, 48, device=DEV)
+    with pytest.raises(T2HError, match='multiple of 32'):
+        ops.gemm(a, torch.zeros(32, 48, device=DEV))
+    with pytest.raises(TypeError):
+        ops.gemm(a.double(), torch.zeros(32, 48, device=DEV))
+    with pytest.raises(ValueError):
+        ops.gemm(torch.zeros(64, 64, device=DEV).t(), torch.zeros(32, 64, device=DEV))
+    with pytest.raises(T2HError, match='T='):
+        ops.mha_noncausal(torch.zeros(2 * 100, 1536, device=DEV), 2, 100, 8)
+    with pytest.raises(T2HError, match='unsupported'):
+        ops.layernorm(torch.zeros(8, 384, device=DEV), torch.ones(384, device=DEV), torch.zeros(384, device=DEV))

@@ -86,11 +86,15 @@ class VQGANStack:
         sc, sh = self._gn(t, f'{nm}.norm_out', n_img, h * w)
         return self._conv(t, f'{nm}.conv_out', n_img, h, w, pro=(sc, sh, PRO_SWISH)), h, w
 
-    def decode(self, z, n_img, h, w, bot_h=None):
+    def decode(self, z, n_img, h, w, bot_h=None, upscale=False):
         """Decoder.forward (vqgan_arch.py:1000-1033).  `bot_h` is added in the
-        epilogue of the level-4 Upsample conv (:1021-1024)."""
+        epilogue of the level-4 Upsample conv (:1021-1024).  upscale=True feeds
+        the nearest-x2 upsampled latent (fused into conv_in's operand load): the
+        1024x512 interpretation of SURVEY.md 8(d), config 5."""
         nm = self.name
-        t = self._conv(z, f'{nm}.conv_in', n_img, h, w)
+        t = self._conv(z, f'{nm}.conv_in', n_img, h, w, mode='up' if upscale else 'same')
+        if upscale:
+            h, w = 2 * h, 2 * w
         t = self._mid(t, n_img, h, w)
         levels = [lv for lv in self.desc['levels'] if lv['kind'] == 'up']
         for lv in sorted(levels, key=lambda d: -d['level']):
@@ -108,9 +112,11 @@ class VQGANStack:
         sc, sh = self._gn(t, f'{nm}.norm_out', n_img, h * w)
         return self._conv(t, f'{nm}.conv_out', n_img, h, w, pro=(sc, sh, PRO_SWISH)), h, w
 
-    def decode_res(self, z, n_img, h, w):
+    def decode_res(self, z, n_img, h, w, upscale=False):
         """DecoderRes.forward (vqgan_arch.py:1136-1151)."""
-        t = self._conv(z, f'{self.name}.conv_in', n_img, h, w)
+        t = self._conv(z, f'{self.name}.conv_in', n_img, h, w, mode='up' if upscale else 'same')
+        if upscale:
+            h, w = 2 * h, 2 * w
         return self._mid(t, n_img, h, w)
 
 

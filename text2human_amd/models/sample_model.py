@@ -122,7 +122,7 @@ class BaseSampleModel():
         return [lists[i].view(b, self.shape[0], self.shape[1]) for i in range(lists.shape[0])]
 
     # ------------------------------------------------------------ stage D
-    def _decode(self, top_lists, tex_tok, b, want_u8=False, return_inter=False):
+    def _decode(self, top_lists, tex_tok, b, want_u8=False, return_inter=False, upscale=False):
         """sample_and_refine body after sample_fn (models/sample_model.py:220-246),
         batched.  top_lists int64 [18, b*512]."""
         P = self.P
@@ -131,25 +131,29 @@ class BaseSampleModel():
         bot_lists = self._bot_indices(top_quant, tex_tok, b)
         quant_bot = ops.codebook_gather_fold(bot_lists, tex_tok.reshape(-1), P['bot.books'], b, h, w)
         quant_bot = ops.gemm(quant_bot, P['bot.pq.w'], bias=P['bot.pq.b'])
-        bot_h = self.bot_decoder_res.decode_res(quant_bot, b, 2 * h, 2 * w)
-        dec, ho, wo = self.decoder.decode(top_quant, b, h, w, bot_h=bot_h)
+        bot_h = self.bot_decoder_res.decode_res(quant_bot, b, 2 * h, 2 * w, upscale=upscale)
+        dec, ho, wo = self.decoder.decode(top_quant, b, h, w, bot_h=bot_h, upscale=upscale)
         img, u8 = ops.image_epilogue(dec, b, ho, wo, want_u8=want_u8)
         if return_inter:
             return img, u8, dict(top_quant=top_quant, bot_lists=bot_lists, bot_h=bot_h, dec=dec)
         return img, u8
 
     @torch.no_grad()
-    def decode_indices(self, top_indices_list, want_u8=False, return_inter=False):
-        """Batched refine + decode of sampled top indices (list of 18 [B,512])."""
+    def decode_indices(self, top_indices_list, want_u8=False, return_inter=False, upscale=False):
+        """Batched refine + decode of sampled top indices (list of 18 [B,512]).
+        upscale=True: 1024x512 output -- both quantised latents are nearest-x2
+        upsampled before the (fully convolutional) decoders, the interpretation
+        of BASELINE.json configs[4] given in SURVEY.md 8(d)."""
         b = self.batch_size
         tex_tok = self._texture_tokens(self.texture_mask)
         top = torch.stack([t.reshape(-1) for t in top_indices_list]).contiguous()
         imgs, u8s, inters = [], [], []
         t_len = self.shape[0] * self.shape[1]
-        for s in range(0, b, DECODE_CHUNK):
-            e = min(b, s + DECODE_CHUNK)
+        chunk = max(1, DECODE_CHUNK // (4 if upscale else 1))
+        for s in range(0, b, chunk):
+            e = min(b, s + chunk)
             res = self._decode(top[:, s * t_len:e * t_len].contiguous(), tex_tok[s:e], e - s,
-                               want_u8=want_u8, return_inter=return_inter)
+                               want_u8=want_u8, return_inter=return_inter, upscale=upscale)
             imgs.append(res[0])
             u8s.append(res[1])
             if return_inter:
