@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense (NOT the 2:1-sparse figure)
 
 
 def parse_args():
@@ -108,12 +109,17 @@ def pmc_traffic(kernel_label):
     tools/pmc_summary.py) -- launch-weighted over the kernel's shapes."""
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
     m = __import__('re').match(r'gemm_kernel<(\d+)x(\d+)x(\d+)(w8)?,amode=(\d),pro=(\d),btrans=(\d)>', kernel_label)
-    if not (os.path.exists(path) and m):
+    if not os.path.exists(path):
         return {'traffic': None}
-    bm, bn, bk, w8, am, pro, bt = m.groups()
-    wm, wn = ('4', '2') if w8 else (('4', '1') if bn == '32' else ('2', '2'))
-    name = f'gemm_kernel<{bm}, {bn}, {bk}, {wm}, {wn}, {am}, {pro}, {"true" if bt == "1" else "false"}>'
-    rows = [r for r in json.load(open(path)) if r['kernel'] == name]
+    if kernel_label.startswith('gemm_split'):
+        rows = [r for r in json.load(open(path)) if r['kernel'].startswith('gemm_split_kernel')]
+    elif m:
+        bm, bn, bk, w8, am, pro, bt = m.groups()
+        wm, wn = ('4', '2') if w8 else (('4', '1') if bn == '32' else ('2', '2'))
+        name = f'gemm_kernel<{bm}, {bn}, {bk}, {wm}, {wn}, {am}, {pro}, {"true" if bt == "1" else "false"}>'
+        rows = [r for r in json.load(open(path)) if r['kernel'] == name]
+    else:
+        return {'traffic': None}
     if not rows:
         return {'traffic': None}
     n = sum(r['launches'] for r in rows)
@@ -202,7 +208,9 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': ('f32' if os.environ.get('T2H_SPLIT_GEMM', '1') == '0' else
+                  'f32 (sampler Linears as 3xbf16-split MFMA with fp32 accumulate: fp32-class accuracy, '
+                  'tokens bit-exact vs the fp32 oracle; everything else exact-fp32 MFMA)'),
         'data': 'synthetic',
         'config': {
             'workload': (f'sample_from_parsing.yml batch={args.batch}/GPU, {args.sample_steps} sampling '
@@ -217,12 +225,20 @@ def main():
     # dominant kernel = the GEMM instantiation with the largest total sampled time
     if prof:
         dom = max(prof.values(), key=lambda r: r['ms'])
-        ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        eq = dom['flops'] / (dom['ms'] * 1e-3) / 1e12  # fp32-equivalent 2*M*N*K per launch / time
+        split = dom['kernel'].startswith('gemm_split')
+        # The split-precision kernel's algorithm is six bf16 x bf16 partial products per
+        # fp32 multiply on v_mfma_f32_32x32x16_bf16, so its matrix-core roofline is the
+        # dense bf16 peak and its algorithmic work 6 * 2*M*N*K; the fp32-equivalent rate
+        # and its ratio to the fp32-MFMA peak are reported next to it.
+        mult, peak = (6.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        ach = eq * mult
         out['roofline'] = {
-            'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+            'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': peak,
+            'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+            'fp32_equivalent_tflops': eq, 'frac_of_fp32_mfma_peak': eq / FP32_MFMA_PEAK_TFLOPS,
             'launches_sampled': dom['n'], 'avg_launch_us': 1000.0 * dom['ms'] / dom['n'],
-            'flop_per_launch': dom['flops'] / dom['n'],
+            'flop_per_launch': mult * dom['flops'] / dom['n'],
             'all_gemm_kernels': {k: {'TFLOP/s': v['flops'] / (v['ms'] * 1e-3) / 1e12, 'n': v['n'],
                                      'avg_us': 1000.0 * v['ms'] / v['n']} for k, v in prof.items()},
         }

@@ -78,6 +78,15 @@ typedef struct t2h_gemm_args {
   int32_t ups;            /* 1: input is nearest-upsampled x2 on the fly */
   int32_t batch;          /* >=1: independent problems (blockIdx.z) */
   int64_t strideA, strideB, strideC; /* element strides between problems */
+  /* Fused LayerNorm (transformer_arch.py:80-81,93-95): rows of A are normalised on
+   * the fly, a' = (a - mean_r) * rstd_r, from per-row partial statistics
+   * [M][K/32][2] = (sum, sum of squares) per 32-column slab; gamma/beta are folded
+   * into B / bias by the caller.  Plain GEMM (a_mode 0, no tables, no b_trans). */
+  const float* ln_stats_in;
+  /* If set, the epilogue writes the same statistics of the OUTPUT rows,
+   * [M][N/32][2], for the next GEMM (N % 32 == 0). */
+  float* ln_stats_out;
+  float ln_eps;
 } t2h_gemm_args;
 
 int t2h_gemm_f32(const t2h_gemm_args* args, void* stream);
@@ -88,6 +97,36 @@ int t2h_gemm_tile_config(const t2h_gemm_args* args);
 /* tuning hook: force a configuration id for every following GEMM whose shape
  * supports it (-1 = automatic); returns the previous setting */
 int t2h_gemm_force_config(int cfg);
+
+/* ------------------------------------------------- split-precision GEMM -----
+ * Same contraction on the bf16 matrix cores at fp32-class accuracy: every fp32
+ * operand is carried as three bf16 planes (x = x0 + x1 + x2) and a product is the
+ * six partial products of order >= 2^-18 (v_mfma_f32_32x32x16_bf16, fp32
+ * accumulate).  Operands are "split rows": [rows][K/32][3][32] bf16 (192 B per
+ * row and 32-wide K tile), written by t2h_split3_f32 / the C_split epilogue.
+ * Replaces the same nn.Linear call sites as t2h_gemm_f32 (opt-in fast path). */
+typedef struct t2h_gemm_split_args {
+  const uint16_t* A;      /* split rows [M][K/32][3][32] */
+  const uint16_t* B;      /* split rows [N][K/32][3][32] (weights, repacked once) */
+  float* C;               /* fp32 output [M,N] ldc, or NULL */
+  uint16_t* C_split;      /* split-row output [M][N/32][3][32], or NULL */
+  const float* bias;      /* [N] or NULL */
+  const float* residual;  /* fp32 [M,N] ldr or NULL (added after the activation) */
+  int32_t M, N, K;
+  int32_t ldc, ldr;
+  int32_t epi_act;        /* 0 none, 1 GELU(erf), 2 ReLU */
+} t2h_gemm_split_args;
+
+int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
+int t2h_gemm_split_force_config(int cfg); /* tuning: 0 128x64/4 waves, 1 128x128/8 waves, -1 auto */
+/* fp32 [rows, C] (row stride ldx) -> split rows */
+int t2h_split3_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);
+/* producers that emit split rows directly: LayerNorm (transformer_arch.py:93-95)
+ * and the attention output (transformer_arch.py:65-67) */
+int t2h_layernorm_split_f32(const float* x, const float* gamma, const float* beta, uint16_t* y_split,
+                            int32_t rows, int32_t C, float eps, void* stream);
+int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, int32_t T,
+                                int32_t n_head, void* stream);
 
 /* ------------------------------------------------------ normalisation ------
  * LayerNorm over the last dim (eps 1e-5): transformer_arch.py:80-81,93-95,231,270 */
@@ -102,6 +141,11 @@ int t2h_groupnorm_tables_f32(const float* x, int32_t ldx, const float* gamma,
                              const float* beta, float* scale, float* shift,
                              int32_t n_img, int32_t HW, int32_t C, int32_t groups,
                              float eps, void* workspace, void* stream);
+
+/* per-row, per-32-column-slab (sum, sum of squares) of x[rows, C] -> stats
+ * [rows][C/32][2]: seeds the fused-LayerNorm statistics (t2h_gemm_args.ln_stats_in)
+ * for a tensor that did not come out of a GEMM epilogue (the embedding sum) */
+int t2h_row_stats_f32(const float* x, float* stats, int32_t rows, int32_t C, void* stream);
 
 /* in-place row softmax of [rows, n] (AttnBlock, vqgan_arch.py:647) */
 int t2h_softmax_rows_f32(float* x, int32_t rows, int32_t n, int32_t ld, void* stream);

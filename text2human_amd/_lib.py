@@ -32,11 +32,25 @@ class GemmArgs(ctypes.Structure):
         ('Hin', c_i32), ('Win', c_i32), ('Cin', c_i32), ('Hout', c_i32), ('Wout', c_i32),
         ('stride', c_i32), ('pad', c_i32), ('ups', c_i32), ('batch', c_i32),
         ('strideA', c_i64), ('strideB', c_i64), ('strideC', c_i64),
+        ('ln_stats_in', c_vp), ('ln_stats_out', c_vp), ('ln_eps', c_f32),
+    ]
+
+
+class GemmSplitArgs(ctypes.Structure):
+    """struct t2h_gemm_split_args (include/t2h_hip.h)."""
+    _fields_ = [
+        ('A', c_vp), ('B', c_vp), ('C', c_vp), ('C_split', c_vp), ('bias', c_vp), ('residual', c_vp),
+        ('M', c_i32), ('N', c_i32), ('K', c_i32), ('ldc', c_i32), ('ldr', c_i32), ('epi_act', c_i32),
     ]
 
 
 # name -> (restype, argtypes); must list EVERY symbol declared in include/t2h_hip.h
 SIGNATURES = {
+    't2h_gemm_split_f32': (ctypes.c_int, [ctypes.POINTER(GemmSplitArgs), c_vp]),
+    't2h_gemm_split_force_config': (ctypes.c_int, [ctypes.c_int]),
+    't2h_split3_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i32, c_vp]),
+    't2h_layernorm_split_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
+    't2h_mha_noncausal_split_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_version': (ctypes.c_int, []),
     't2h_last_error': (ctypes.c_char_p, []),
     't2h_gemm_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp]),
@@ -46,6 +60,7 @@ SIGNATURES = {
     't2h_groupnorm_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32]),
     't2h_groupnorm_tables_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                                 c_i32, c_i32, c_f32, c_vp, c_vp]),
+    't2h_row_stats_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     't2h_softmax_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_embed_sum4_f32': (ctypes.c_int, [c_vp] * 8 + [c_i32, c_i32, c_i32, c_vp]),
     't2h_mha_noncausal_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

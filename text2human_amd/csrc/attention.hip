@@ -35,7 +35,7 @@ constexpr int KV_TILE = KT * K_LD + KT * V_LD;  // floats per (K,V) tile pair
 
 __global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
                                                   float* __restrict__ y, int T, int C,
-                                                  int n_head) {
+                                                  int n_head, uint16_t* __restrict__ y_split) {
   // [2 key halves][K tile | V tile]; reused at the end: [0, 8192) partial O of
   // the second key half, [8192, 8192 + 4*32*O_LD) output transpose staging.
   __shared__ __attribute__((aligned(16))) float smem[2 * KV_TILE];
@@ -201,12 +201,14 @@ __global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
   }
   __syncthreads();
   if (kh == 0) {
-    float* yb = y + ((int64_t)b * T + q0) * C + head * HD;
+    // fp32 rows and / or split rows (operand of the split-precision proj GEMM)
+    const int64_t grow = (int64_t)b * T + q0;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-      *reinterpret_cast<f32x4*>(yb + (int64_t)row * C + c4) =
-          *reinterpret_cast<const f32x4*>(Os + row * O_LD + c4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c4);
+      if (y) *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c4) = v;
+      if (y_split) t2h_store_split4(y_split, grow + row, C, head * HD + c4, v);
     }
   }
 }
@@ -221,7 +223,22 @@ extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int3
   T2H_REQUIRE(t2h_aligned16(qkv) && t2h_aligned16(y), "t2h_mha_noncausal_f32: 16-byte alignment");
   const int C = n_head * HD;
   dim3 grid((T / QB) * n_head * B), block(512);
-  hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv, y, T, C, n_head);
+  hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv, y, T, C, n_head,
+                     static_cast<uint16_t*>(nullptr));
   T2H_CHECK_LAUNCH("t2h_mha_noncausal_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, int32_t T,
+                                           int32_t n_head, void* stream) {
+  T2H_REQUIRE(qkv && y_split, "t2h_mha_noncausal_split_f32: NULL pointer");
+  T2H_REQUIRE(B > 0 && n_head > 0, "t2h_mha_noncausal_split_f32: empty problem");
+  T2H_REQUIRE(T > 0 && T % QB == 0, "t2h_mha_noncausal_split_f32: T=%d must be a multiple of %d", T, QB);
+  T2H_REQUIRE(t2h_aligned16(qkv) && t2h_aligned16(y_split), "t2h_mha_noncausal_split_f32: 16-byte alignment");
+  const int C = n_head * HD;
+  dim3 grid((T / QB) * n_head * B), block(512);
+  hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv,
+                     static_cast<float*>(nullptr), T, C, n_head, y_split);
+  T2H_CHECK_LAUNCH("t2h_mha_noncausal_split_f32");
   return T2H_OK;
 }

@@ -1,0 +1,335 @@
+// fp32-accurate GEMM on the bf16 matrix cores ("3xbf16 split", 6 products).
+//
+//   C[M,N] = epi(A[M,K] * B[N,K]^T + bias) + residual
+//
+// Every fp32 operand x is carried as three bf16 planes x = x0 + x1 + x2
+// (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 3 x 8 = 24 mantissa
+// bits, i.e. the fp32 value itself up to 2^-25 relative).  A product a*b is
+// evaluated as the six partial products whose order is >= 2^-18
+//   a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0          (dropped: a1b2, a2b1, a2b2 <= 2^-26)
+// each an exact bf16 x bf16 product accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Six MFMAs at 16x the fp32-MFMA rate = 2.67x the
+// matrix throughput of v_mfma_f32_32x32x2_f32 at fp32-class accuracy.
+//
+// Operand layout in HBM ("split rows"): [rows][K/32][3 planes][32 k] bf16, i.e. 192
+// contiguous bytes per (row, 32-wide K tile): the producers (LayerNorm, GELU /
+// attention epilogues, the weight repacker) write it directly, and a K tile of a
+// row is staged global -> LDS as twelve 16-byte pieces without any conversion.
+// LDS rows are padded to 208 B (13 slots of 16 B, odd) so the per-lane 16-byte
+// fragment reads (ds_read_b128, 8 consecutive k of one plane) are conflict free.
+// Main loop = the same two-register-set, counted-vmcnt software pipeline as the
+// fp32 kernel (gemm.hip): staged pieces are written to LDS and re-issued in the
+// shadow of the MFMAs.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SP_TILE_B = 192;   // bytes per (row, K tile) in HBM
+constexpr int SP_LDS_ROW = 208;  // bytes per row in LDS
+constexpr int SP_PIECES = 12;    // 16-byte pieces per (row, K tile)
+
+__device__ __forceinline__ void gload16_async(u32x4& dst, const char* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt16(u32x4& v) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+__device__ __forceinline__ float gelu_erf_s(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_split_kernel(const t2h_gemm_split_args p) {
+  constexpr int NT = 64 * WARPS_M * WARPS_N;
+  constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
+  constexpr int A_P = BM * SP_PIECES / NT;  // 16-byte pieces per thread and K tile
+  constexpr int B_P = BN * SP_PIECES / NT;
+  static_assert(A_P * NT == BM * SP_PIECES && B_P * NT == BN * SP_PIECES, "bad staging shape");
+  constexpr int L = A_P + B_P;
+  constexpr int NMMA = 2 * 6 * TM * TN;  // MFMAs per wave and K tile
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * SP_LDS_ROW];
+  char* const As = smem;
+  char* const Bs = smem + 2 * BM * SP_LDS_ROW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wm0 = (wave / WARPS_N) * WM, wn0 = (wave % WARPS_N) * WN;
+  // XCD-aware tile mapping (see gemm.hip)
+  const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int total = nbx * nby, b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3, q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int mt = lin / nbx;
+    m0 = mt * BM;
+    n0 = (lin - mt * nbx) * BN;
+  }
+  const int nk = p.K / 32;
+  const int last = nk - 1;
+  const int64_t row_b = (int64_t)nk * SP_TILE_B;  // bytes per split row
+
+  // ---- per-thread staging slots (fixed for the whole kernel)
+  const char* a_src[A_P];
+  const char* b_src[B_P];
+  int a_dst[A_P], b_dst[B_P];
+  unsigned a_ok = 0u, b_ok = 0u;
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    const int q = tid + NT * i, row = q / SP_PIECES, pc = q - row * SP_PIECES;
+    const bool ok = m0 + row < p.M;
+    a_src[i] = reinterpret_cast<const char*>(p.A) + (int64_t)(ok ? m0 + row : 0) * row_b + pc * 16;
+    a_dst[i] = row * SP_LDS_ROW + pc * 16;
+    if (ok) a_ok |= 1u << i;
+  }
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    const int q = tid + NT * i, row = q / SP_PIECES, pc = q - row * SP_PIECES;
+    const bool ok = n0 + row < p.N;
+    b_src[i] = reinterpret_cast<const char*>(p.B) + (int64_t)(ok ? n0 + row : 0) * row_b + pc * 16;
+    b_dst[i] = row * SP_LDS_ROW + pc * 16;
+    if (ok) b_ok |= 1u << i;
+  }
+  u32x4 ra[2][A_P], rb[2][B_P];
+  // Rows beyond M / N are loaded from a clamped (valid) address and NOT masked: an
+  // output element depends only on its own A row and B row, and rows / columns
+  // beyond the problem are never stored, so whatever they contain is harmless.
+  (void)a_ok;
+  (void)b_ok;
+  auto put_a = [&](int i, const u32x4& r, int buf) {
+    *reinterpret_cast<u32x4*>(As + buf * BM * SP_LDS_ROW + a_dst[i]) = r;
+  };
+  auto put_b = [&](int i, const u32x4& r, int buf) {
+    *reinterpret_cast<u32x4*>(Bs + buf * BN * SP_LDS_ROW + b_dst[i]) = r;
+  };
+  auto issue = [&](auto setc, int kt) {
+    constexpr int S = decltype(setc)::value;
+    const int64_t k0 = (int64_t)min(kt, last) * SP_TILE_B;
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) gload16_async(rb[S][i], b_src[i] + k0);
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) gload16_async(ra[S][i], a_src[i] + k0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  using set0 = std::integral_constant<int, 0>;
+  using set1 = std::integral_constant<int, 1>;
+  issue(set0{}, 0);
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    wait_vmcnt16<0>(rb[0][i]);
+    put_b(i, rb[0][i], 0);
+  }
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    wait_vmcnt16<0>(ra[0][i]);
+    put_a(i, ra[0][i], 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  issue(set1{}, 1);
+  issue(set0{}, 2);
+  __syncthreads();
+
+  // partial products in increasing magnitude: (a2,b0) (a0,b2) (a1,b1) (a1,b0) (a0,b1) (a0,b0)
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+  auto step = [&](int kt, auto setc) {  // register set S holds tile kt+1
+    constexpr int S = decltype(setc)::value;
+    const int buf = kt & 1;
+    const int64_t kn = (int64_t)min(kt + 3, last) * SP_TILE_B;
+    const char* Ab = As + buf * BM * SP_LDS_ROW + (wm0 + l31) * SP_LDS_ROW + hh * 16;
+    const char* Bb = Bs + buf * BN * SP_LDS_ROW + (wn0 + l31) * SP_LDS_ROW + hh * 16;
+    int mma = 0;  // running MFMA count inside the tile (compile-time after unrolling)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {  // two k16 steps per K tile
+      bf16x8 af[TM][3], bfr[TN][3];
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          af[ti][pl] = *reinterpret_cast<const bf16x8*>(Ab + ti * 32 * SP_LDS_ROW + pl * 64 + u * 32);
+#pragma unroll
+      for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bfr[tj][pl] = *reinterpret_cast<const bf16x8*>(Bb + tj * 32 * SP_LDS_ROW + pl * 64 + u * 32);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TN; ++tj) {
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti][PA[t]], bfr[tj][PB[t]],
+                                                                   acc[ti][tj], 0, 0, 0);
+            ++mma;
+            // staged pieces pinned behind the MFMAs of the second half of the tile
+#pragma unroll
+            for (int q = 0; q < L; ++q) {
+              const int at = (2 * L <= NMMA) ? NMMA - 2 * (L - q) + 1 : (NMMA * (q + 1)) / L;
+              if (at != mma) continue;
+              __builtin_amdgcn_sched_barrier(0);
+              if (q < B_P) {
+                wait_vmcnt16<2 * L - 1>(rb[S][q]);
+                put_b(q, rb[S][q], buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                gload16_async(rb[S][q], b_src[q] + kn);
+              } else {
+                wait_vmcnt16<2 * L - 1>(ra[S][q - B_P]);
+                put_a(q - B_P, ra[S][q - B_P], buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                gload16_async(ra[S][q - B_P], a_src[q - B_P] + kn);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      }
+    }
+    __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    step(kt, set1{});
+    step(kt + 1, set0{});
+  }
+  if (nk & 1) step(nk - 1, set1{});
+#pragma unroll
+  for (int S = 0; S < 2; ++S) {
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) wait_vmcnt16<0>(rb[S][i]);
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) wait_vmcnt16<0>(ra[S][i]);
+  }
+
+  // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (r&3) +
+  // 8*(r>>2) + 4*(lane>>5)) are transposed through the (now idle) LDS so that every
+  // lane owns 4 CONSECUTIVE columns of a row: residual loads and fp32 stores become
+  // 16-byte accesses and a split-row store is three 8-byte writes instead of twelve
+  // 2-byte ones.
+  constexpr int O_LD = WN + 4;  // floats per staged row (odd number of 16-B slots)
+  static_assert(64 * WARPS_M * WARPS_N * 0 + WM * O_LD * 4 * WARPS_M * WARPS_N <= 2 * (BM + BN) * SP_LDS_ROW,
+                "epilogue staging must fit in the tile buffers");
+  float* const Ot = reinterpret_cast<float*>(smem) + wave * (WM * O_LD);
+#pragma unroll
+  for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TN; ++tj) {
+      const int col = n0 + wn0 + tj * 32 + l31;
+      const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Ot[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = acc[ti][tj][r] + bv;
+    }
+  __syncthreads();
+  constexpr int CPR = WN / 4;              // float4 chunks per staged row
+  constexpr int NCH = WM * CPR / 64;       // chunks per lane
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int c = lane + 64 * it;
+    const int rl = c / CPR, c4 = (c - rl * CPR) * 4;
+    const int row = m0 + wm0 + rl, col = n0 + wn0 + c4;
+    if (row >= p.M || col >= p.N) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p.epi_act == 1) v[e] = gelu_erf_s(v[e]);
+      else if (p.epi_act == 2) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
+    if (p.C) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
+    if (p.C_split) t2h_store_split4(p.C_split, row, p.N, col, v);
+  }
+}
+
+// fp32 [rows, C] (ld) -> split rows; one thread per 4 consecutive columns
+__global__ void split3_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ out, int64_t total,
+                              int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over rows * C/4
+  if (i >= total) return;
+  const int q = C >> 2;
+  const int64_t row = i / q;
+  const int c0 = (int)(i - row * q) * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c0);
+  __bf16 s[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t2h_split3(v[e], s[0][e], s[1][e], s[2][e]);
+  char* d = reinterpret_cast<char*>(out) + row * (int64_t)(C / 32) * SP_TILE_B + (c0 >> 5) * SP_TILE_B +
+            (c0 & 31) * 2;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 w = {s[pl][0], s[pl][1], s[pl][2], s[pl][3]};
+    *reinterpret_cast<bf16x4*>(d + pl * 64) = w;
+  }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
+  dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N>), grid, dim3(64 * WARPS_M * WARPS_N), 0, s, a);
+  T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
+  return T2H_OK;
+}
+
+int g_force_split_cfg = -1;
+
+}  // namespace
+
+extern "C" int t2h_gemm_split_force_config(int cfg) {
+  const int old = g_force_split_cfg;
+  g_force_split_cfg = cfg;
+  return old;
+}
+
+extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream) {
+  T2H_REQUIRE(args != nullptr, "t2h_gemm_split_f32: args is NULL");
+  const t2h_gemm_split_args a = *args;
+  T2H_REQUIRE(a.A && a.B && (a.C || a.C_split), "t2h_gemm_split_f32: NULL operand");
+  T2H_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0, "t2h_gemm_split_f32: bad shape M=%d N=%d K=%d",
+              a.M, a.N, a.K);
+  T2H_REQUIRE(t2h_aligned16(a.A) && t2h_aligned16(a.B), "t2h_gemm_split_f32: operands must be 16-byte aligned");
+  T2H_REQUIRE(a.N % 4 == 0 && (!a.C || (a.ldc % 4 == 0 && t2h_aligned16(a.C))) &&
+                  (!a.residual || (a.ldr % 4 == 0 && t2h_aligned16(a.residual))),
+              "t2h_gemm_split_f32: N, ldc, ldr must be multiples of 4 and C / residual 16-byte aligned");
+  if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int cfg = g_force_split_cfg;
+  if (cfg < 0) {
+    // measured on MI355X at M = 4096 (tools/gemm_split_bench.py): the 4-wave 128x64
+    // tile wins on every sampler shape; 128x128 only pays once it still fills 2x256 CUs
+    const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    cfg = a.M <= 64 ? 2 : (tiles128 >= 1024 ? 1 : 0);
+  }
+  switch (cfg) {
+    case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64
+    case 2: return launch_split<64, 64, 2, 2>(a, s);    // 4 waves, wave tile 32x32
+    default: return launch_split<128, 64, 2, 2>(a, s);  // 4 waves, wave tile 64x32
+  }
+}
+
+extern "C" int t2h_split3_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream) {
+  T2H_REQUIRE(x && out && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0, "t2h_split3_f32: bad arguments");
+  const int64_t total = rows * (C / 4);
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, ldx, out, total, C);
+  T2H_CHECK_LAUNCH("t2h_split3_f32");
+  return T2H_OK;
+}

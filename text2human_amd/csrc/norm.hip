@@ -5,7 +5,9 @@ namespace {
 
 // One wave per row; each lane keeps its C/64 values in registers, two passes
 // (mean, then centred variance) like torch's rowwise moments.
-template <int VPL>  // float4 vectors per lane: C = 256 * VPL
+// SPLIT: the result is written as split rows (three bf16 planes) for the
+// split-precision GEMM instead of fp32.
+template <int VPL, bool SPLIT = false>  // float4 vectors per lane: C = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-    *reinterpret_cast<f32x4*>(yr + i * 256 + lane * 4) = o;
+    if (SPLIT) t2h_store_split4(reinterpret_cast<uint16_t*>(y), row, C, i * 256 + lane * 4, o);
+    else *reinterpret_cast<f32x4*>(yr + i * 256 + lane * 4) = o;
   }
 }
 
@@ -185,6 +188,27 @@ extern "C" int t2h_layernorm_f32(const float* x, const float* gamma, const float
     return T2H_ERR_UNSUPPORTED;
   }
   T2H_CHECK_LAUNCH("t2h_layernorm_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_layernorm_split_f32(const float* x, const float* gamma, const float* beta,
+                                       uint16_t* y_split, int32_t rows, int32_t C, float eps,
+                                       void* stream) {
+  T2H_REQUIRE(x && gamma && beta && y_split, "t2h_layernorm_split_f32: NULL pointer");
+  T2H_REQUIRE(rows > 0, "t2h_layernorm_split_f32: rows=%d", rows);
+  T2H_REQUIRE(t2h_aligned16(x) && t2h_aligned16(y_split) && t2h_aligned16(gamma) && t2h_aligned16(beta),
+              "t2h_layernorm_split_f32: 16-byte alignment");
+  dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* y = reinterpret_cast<float*>(y_split);
+  if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps);
+  else if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps);
+  else if (C == 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps);
+  else {
+    t2h_set_error("t2h_layernorm_split_f32: C=%d unsupported (256/512/1024)", C);
+    return T2H_ERR_UNSUPPORTED;
+  }
+  T2H_CHECK_LAUNCH("t2h_layernorm_split_f32");
   return T2H_OK;
 }
 

@@ -129,15 +129,25 @@ class SamplerNet:
     tail kernel.  24 x [LN, QKV GEMM, flash MHA, proj GEMM(+res), LN, fc1
     GEMM(+GELU), fc2 GEMM(+res)]."""
 
-    def __init__(self, P, desc, n_head, name='tf'):
+    def __init__(self, P, desc, n_head, name='tf', fuse_ln=False, split=False):
         self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
+        self.split = split
+        # fuse_ln: LayerNorm folded into the GEMM operand staging + statistics from
+        # the producer's epilogue.  Parity-tested, but MEASURED SLOWER at B=8 on
+        # MI355X (2042 vs 1961 ms per batch: the statistics prologue/epilogue cost
+        # the K=512 GEMMs more than the 48 LayerNorm launches per step save), so
+        # the separate LayerNorm kernel stays the default.
+        self.fuse_ln = fuse_ln
         self._buf = {}
 
     def _buffers(self, M, C, dev):
         key = (M, C, str(dev))
         if key not in self._buf:
             e = lambda n: torch.empty((M, n), device=dev, dtype=torch.float32)
-            self._buf = {key: dict(x=e(C), h=e(C), qkv=e(3 * C), y=e(C), u=e(4 * C))}
+            self._buf = {key: dict(x=e(C), h=e(C), qkv=e(3 * C), y=e(C), u=e(4 * C),
+                                   stats=torch.empty((M, C // 32, 2), device=dev, dtype=torch.float32),
+                                   h_split=ops.split_rows_empty(M, C, dev), y_split=ops.split_rows_empty(M, C, dev),
+                                   u_split=ops.split_rows_empty(M, 4 * C, dev))}
         return self._buf[key]
 
     def hidden(self, idx, segm_tok, tex_tok):
@@ -148,6 +158,40 @@ class SamplerNet:
         x, h, qkv, y, u = buf['x'], buf['h'], buf['qkv'], buf['y'], buf['u']
         ops.embed_sum4(idx, segm_tok, tex_tok, P[f'{nm}.tok_emb'], P[f'{nm}.pos_emb'],
                        P[f'{nm}.segm_emb'], P[f'{nm}.tex_emb'], out=x)
+        if self.split:
+            # Split-precision path: the four Linears run on the bf16 matrix cores with
+            # 3 x bf16 planes per operand (fp32-class accuracy, gemm_split.hip).  The
+            # producers write split rows directly: LayerNorm -> h, attention -> y,
+            # fc1's GELU epilogue -> u; the residual stream x and q|k|v stay fp32.
+            M = B * T
+            hs, ys, us = buf['h_split'], buf['y_split'], buf['u_split']
+            for i in range(self.desc['n_layers']):
+                p = f'{nm}.{i}'
+                ops.layernorm_split(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs)
+                ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out=qkv, bias=P[f'{p}.qkv.b'])
+                ops.mha_noncausal_split(qkv, B, T, self.n_head, ys)
+                ops.gemm_split(ys, P[f'{p}.proj.w_split'], M, C, C, out=x, bias=P[f'{p}.proj.b'], residual=x)
+                ops.layernorm_split(x, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs)
+                ops.gemm_split(hs, P[f'{p}.fc1.w_split'], M, 4 * C, C, out_split=us, bias=P[f'{p}.fc1.b'],
+                               act=ACT_GELU)
+                ops.gemm_split(us, P[f'{p}.fc2.w_split'], M, C, 4 * C, out=x, bias=P[f'{p}.fc2.b'],
+                               residual=x)
+            return x
+        if self.fuse_ln:
+            # LayerNorm never materialises: the residual GEMMs (proj, fc2) emit the
+            # row statistics of the new x in their epilogue, the next GEMM (QKV, fc1)
+            # normalises its A operand while staging it (gamma/beta folded into W/b).
+            st = buf['stats']
+            ops.row_stats(x, out=st)
+            for i in range(self.desc['n_layers']):
+                p = f'{nm}.{i}'
+                ops.gemm(x, P[f'{p}.qkv.w_ln'], out=qkv, bias=P[f'{p}.qkv.b_ln'], ln_stats_in=st)
+                ops.mha_noncausal(qkv, B, T, self.n_head, out=y)
+                ops.gemm(y, P[f'{p}.proj.w'], out=x, bias=P[f'{p}.proj.b'], residual=x, ln_stats_out=st)
+                ops.gemm(x, P[f'{p}.fc1.w_ln'], out=u, bias=P[f'{p}.fc1.b_ln'], act=ACT_GELU,
+                         ln_stats_in=st)
+                ops.gemm(u, P[f'{p}.fc2.w'], out=x, bias=P[f'{p}.fc2.b'], residual=x, ln_stats_out=st)
+            return x
         for i in range(self.desc['n_layers']):
             p = f'{nm}.{i}'
             ops.layernorm(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], out=h)

@@ -61,7 +61,11 @@ class BaseSampleModel():
         self.index_pred_guidance_encoder = engine.UNetStack(P, 'ipu', d_unet)
         self.ipd = weights.pack_multihead_fcn(P, sds['index_decoder'], 'ipd')
         d_tf = weights.pack_transformer(P, sds['sampler'], 'tf')
-        self.sampler_fn = engine.SamplerNet(P, d_tf, self.opt['bert_n_head'], 'tf')
+        # T2H_SPLIT_GEMM=0 selects the exact-fp32 MFMA GEMMs for the sampler's Linears;
+        # default: split-precision (3 x bf16 planes, six products) on the bf16 matrix
+        # cores -- same fp32-class accuracy (tests/test_gpu_split.py), higher throughput
+        split = os.environ.get('T2H_SPLIT_GEMM', '1') != '0'
+        self.sampler_fn = engine.SamplerNet(P, d_tf, self.opt['bert_n_head'], 'tf', split=split)
 
     # ------------------------------------------------------------ helpers
     def _texture_tokens(self, texture_mask):

@@ -98,7 +98,7 @@ def _launch_gemm(g, what):
 
 
 def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=None,
-         b_trans=False):
+         b_trans=False, ln_stats_in=None, ln_stats_out=None, ln_eps=1e-5):
     """out[M,N] = act(alpha * pro(a)[M,K] @ w[N,K]^T + bias) + residual.
 
     a, w, out, residual: 2-D views with unit inner stride (row stride free).
@@ -124,6 +124,14 @@ def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_rows, g.pro_ld, g.pro_act = rows, sc.shape[1], pact
     g.batch = 1
+    if ln_stats_in is not None:
+        _chk_f32(ln_stats_in)
+        assert ln_stats_in.is_contiguous() and ln_stats_in.numel() == M * (K // 32) * 2
+        g.ln_stats_in, g.ln_eps = ln_stats_in.data_ptr(), ln_eps
+    if ln_stats_out is not None:
+        _chk_f32(ln_stats_out)
+        assert ln_stats_out.is_contiguous() and ln_stats_out.numel() == M * (N // 32) * 2
+        g.ln_stats_out = ln_stats_out.data_ptr()
     _launch_gemm(g, 't2h_gemm_f32')
     return out
 
@@ -192,6 +200,93 @@ def layernorm(x, gamma, beta, out=None, eps=1e-5):
         out = torch.empty_like(x)
     check(_lib.load().t2h_layernorm_f32(_p(x), _p(gamma), _p(beta), _p(out), rows, C, eps, _stream()),
           't2h_layernorm_f32')
+    return out
+
+
+def split_rows_empty(rows, C, device):
+    """Uninitialised split-row buffer [rows][C/32][3][32] bf16 (as int16)."""
+    return torch.empty((rows, C // 32, 3, 32), device=device, dtype=torch.int16)
+
+
+def split3(x, out=None):
+    """fp32 x [rows, C] (unit inner stride) -> split rows (x = x0 + x1 + x2, bf16 planes)."""
+    _chk_f32(x)
+    rows, C = x.shape
+    if out is None:
+        out = split_rows_empty(rows, C, x.device)
+    check(_lib.load().t2h_split3_f32(_p(x), _rows(x), _p(out), rows, C, _stream()), 't2h_split3_f32')
+    return out
+
+
+def pack_split_rows_host(w):
+    """Host-side (torch CPU) repack of an fp32 matrix [N, K] into split rows."""
+    w = w.float()
+    p0 = w.bfloat16()
+    r1 = w - p0.float()
+    p1 = r1.bfloat16()
+    p2 = (r1 - p1.float()).bfloat16()
+    n, k = w.shape
+    planes = torch.stack([p0, p1, p2], 0).view(3, n, k // 32, 32).permute(1, 2, 0, 3).contiguous()
+    return planes.view(torch.int16)
+
+
+def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE):
+    """C = act(A @ W^T + bias) + residual on the bf16 matrix cores at fp32-class
+    accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
+    split-row form `out_split` of the result."""
+    _chk_f32(out, bias, residual)
+    g = _lib.GemmSplitArgs()
+    g.A, g.B = a_split.data_ptr(), w_split.data_ptr()
+    g.C = out.data_ptr() if out is not None else None
+    g.C_split = out_split.data_ptr() if out_split is not None else None
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.residual = residual.data_ptr() if residual is not None else None
+    g.M, g.N, g.K = M, N, K
+    g.ldc = _rows(out) if out is not None else 0
+    g.ldr = _rows(residual) if residual is not None else 0
+    g.epi_act = act
+    lib = _lib.load()
+    if _prof is not None:
+        _prof['count'] += 1
+        if _prof['count'] % _prof['every'] == 0:
+            # algorithmic (fp32-equivalent) FLOPs; the kernel issues 6 bf16 products per multiply
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
+            e1.record()
+            _prof['recs'].append(('gemm_split_kernel<3xbf16>', 2.0 * M * N * K, e0, e1))
+            return out if out is not None else out_split
+    check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
+    return out if out is not None else out_split
+
+
+def layernorm_split(x, gamma, beta, out_split, eps=1e-5):
+    """LayerNorm whose result is written as split rows."""
+    _chk_f32(x, gamma, beta)
+    assert x.is_contiguous()
+    rows, C = x.shape
+    check(_lib.load().t2h_layernorm_split_f32(_p(x), _p(gamma), _p(beta), _p(out_split), rows, C, eps,
+                                              _stream()), 't2h_layernorm_split_f32')
+    return out_split
+
+
+def mha_noncausal_split(qkv, B, T, n_head, out_split):
+    """Attention whose output is written as split rows."""
+    _chk_f32(qkv)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * n_head * 64)
+    check(_lib.load().t2h_mha_noncausal_split_f32(_p(qkv), _p(out_split), B, T, n_head, _stream()),
+          't2h_mha_noncausal_split_f32')
+    return out_split
+
+
+def row_stats(x, out=None):
+    """x [rows, C] -> LayerNorm slab statistics [rows, C/32, 2] (sum, sumsq)."""
+    _chk_f32(x, out)
+    assert x.is_contiguous()
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C // 32, 2), device=x.device, dtype=torch.float32)
+    check(_lib.load().t2h_row_stats_f32(_p(x), _p(out), rows, C, _stream()), 't2h_row_stats_f32')
     return out
 
 

@@ -163,6 +163,22 @@ def pack_transformer(P, sd, dst='tf'):
             P.put(f'{d}.{ln}.b', sd[f'{s}.{ln}.bias'])
         P.put(f'{d}.qkv.w', torch.cat([sd[f'{s}.attn.{n}.weight'] for n in ('query', 'key', 'value')], 0))
         P.put(f'{d}.qkv.b', torch.cat([sd[f'{s}.attn.{n}.bias'] for n in ('query', 'key', 'value')], 0))
+        # split rows (3 x bf16 planes) of the four Linears for the split-precision GEMM
+        from . import ops as _ops
+        for lin, key in (('qkv', None), ('proj', f'{s}.attn.proj.weight'), ('fc1', f'{s}.mlp.0.weight'),
+                         ('fc2', f'{s}.mlp.2.weight')):
+            w = P[f'{d}.qkv.w'].cpu() if key is None else sd[key]
+            P.t[f'{d}.{lin}.w_split'] = _ops.pack_split_rows_host(w).to(P.device)
+        # LayerNorm folded into the following Linear for the fused-LN GEMM:
+        # LN(x) W^T + b = ((x-mean)*rstd) (W diag(gamma))^T + (b + W beta)
+        for ln, lin in (('ln1', 'qkv'), ('ln2', 'fc1')):
+            if lin == 'qkv':
+                w, b = P[f'{d}.qkv.w'].double().cpu(), P[f'{d}.qkv.b'].double().cpu()
+            else:
+                w, b = sd[f'{s}.mlp.0.weight'].double(), sd[f'{s}.mlp.0.bias'].double()
+            g, be = sd[f'{s}.{ln}.weight'].double(), sd[f'{s}.{ln}.bias'].double()
+            P.put(f'{d}.{lin}.w_ln', (w * g[None, :]).float())
+            P.put(f'{d}.{lin}.b_ln', (b + w @ be).float())
         P.put(f'{d}.proj.w', sd[f'{s}.attn.proj.weight'])
         P.put(f'{d}.proj.b', sd[f'{s}.attn.proj.bias'])
         P.put(f'{d}.fc1.w', sd[f'{s}.mlp.0.weight'])
