@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument('--cpu-sampler-steps', type=int, default=8)
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-baseline-worker', action='store_true')
+    ap.add_argument('--eager-gpu-baseline', action='store_true',
+                    help='also time the oracle sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
     return ap.parse_args()
 
 
@@ -99,6 +101,31 @@ def cpu_baseline(sample_steps, n_sub):
     except subprocess.TimeoutExpired:
         return dict(value=None, unit='images/s', cores=threads, kind='port',
                     sample='worker exceeded its 240 s time box')
+
+
+def eager_gpu_baseline(model, batch, sds, n_sub, dev):
+    """The un-tuned GPU baseline of SURVEY.md 8(d): the oracle's sampler (the
+    reference's algorithm as eager PyTorch-ROCm fp32 ops: rocBLAS/hipBLASLt GEMMs,
+    unfused softmax / LayerNorm / GELU / Categorical tail) on this same GPU and batch,
+    n_sub steps, next to this package's sampler on the same n_sub steps."""
+    from oracle import torch_ref as R
+    sd = {k: v.to(dev) for k, v in sds['sampler'].items()}
+    tok = model.segm_tokens.view(batch['segm'].shape[0], -1)
+
+    def timed(fn):
+        fn(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(n_sub)
+        torch.cuda.synchronize()
+        return 1000.0 * (time.perf_counter() - t0) / n_sub
+
+    with torch.no_grad():
+        eager = timed(lambda n: R.sample_fn(tok, batch['texture_mask'], sd, sample_steps=n, noise=R.TorchNoise(dev)))
+    ours = timed(lambda n: model.sample_fn(temp=1, sample_steps=n))
+    return dict(kind='oracle sampler as eager PyTorch-ROCm fp32 on the same GPU', sampler_ms_per_step=eager,
+                this_package_sampler_ms_per_step=ours, speedup=eager / ours,
+                sample=f'B={tok.shape[0]}, {n_sub} sampler steps each (the sampler is 97% of the path)')
 
 
 def pmc_traffic(kernel_label):
@@ -247,6 +274,8 @@ def main():
     out['path_tflops'] = 26.17 * out['value'] / world
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.sample_steps, args.cpu_sampler_steps)
+    if world == 1 and args.eager_gpu_baseline:
+        out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, 16, dev)
     print(json.dumps(out), flush=True)
     if use_dist:
         import torch.distributed as dist

@@ -33,8 +33,15 @@ constexpr int SP_TILE_B = 192;   // bytes per (row, K tile) in HBM
 constexpr int SP_LDS_ROW = 208;  // bytes per row in LDS
 constexpr int SP_PIECES = 12;    // 16-byte pieces per (row, K tile)
 
+// Ablation switches for tools/gemm_split_ablate.py (never defined in the product build):
+// T2H_SDBG_NOGLOAD drops the global loads, _NOPUT the LDS stores, _NOFRAG the LDS
+// fragment reads, _NOMMA the matrix instructions.
 __device__ __forceinline__ void gload16_async(u32x4& dst, const char* ptr) {
+#ifdef T2H_SDBG_NOGLOAD
+  asm volatile("" : "=v"(dst) : "v"(ptr));
+#else
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt16(u32x4& v) {
@@ -45,24 +52,36 @@ __device__ __forceinline__ float gelu_erf_s(float v) {
   return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N>
-__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_split_kernel(const t2h_gemm_split_args p) {
-  constexpr int NT = 64 * WARPS_M * WARPS_N;
+// KS = 2: in-block K split.  Two wave groups of WARPS_M x WARPS_N waves each own the
+// whole BM x BN tile, their own pair of LDS tile buffers and every second K tile (group
+// g takes tiles 2s + g); the partial sums meet in LDS in the epilogue, group 0 first, so
+// the result is deterministic.  It gives a tile that only fills the chip at one block
+// per CU (N = 512 at M = 4096) two waves per SIMD without shrinking the wave tile.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p) {
+  constexpr int NT = 64 * WARPS_M * WARPS_N;  // threads per K group
+  constexpr int NWG = WARPS_M * WARPS_N;      // waves per K group
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
-  constexpr int A_P = BM * SP_PIECES / NT;  // 16-byte pieces per thread and K tile
-  constexpr int B_P = BN * SP_PIECES / NT;
-  static_assert(A_P * NT == BM * SP_PIECES && B_P * NT == BN * SP_PIECES, "bad staging shape");
-  constexpr int L = A_P + B_P;
+  // Staging: the (BM + BN) * 12 16-byte pieces of a K tile (A rows first, then B rows)
+  // are dealt round-robin to the NT threads, L per thread.  When NT does not divide the
+  // piece count the last round wraps around: those threads re-load a piece another
+  // thread also stages and store the identical bytes to the same LDS slot (benign).
+  constexpr int PIECES = (BM + BN) * SP_PIECES;
+  constexpr int L = (PIECES + NT - 1) / NT;
   constexpr int NMMA = 2 * 6 * TM * TN;  // MFMAs per wave and K tile
+  constexpr int BUF_B = (BM + BN) * SP_LDS_ROW;  // bytes per LDS tile buffer: [A rows | B rows]
+  constexpr int O_LD = WN + 4;                   // epilogue staging row (floats), odd # of 16-B slots
+  constexpr int EPI_B = WM * O_LD * 4 * NWG * KS;
+  constexpr int SMEM_B = 2 * BUF_B * KS > EPI_B ? 2 * BUF_B * KS : EPI_B;
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * SP_LDS_ROW];
-  char* const As = smem;
-  char* const Bs = smem + 2 * BM * SP_LDS_ROW;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int kg = KS == 1 ? 0 : (int)threadIdx.x / NT;  // K group
+  const int tid = threadIdx.x - kg * NT;
+  const int lane = tid & 63, wave = tid >> 6;  // wave index inside the group
+  char* const gsm = smem + kg * (2 * BUF_B);   // this group's tile buffers
   const int l31 = lane & 31, hh = lane >> 5;
   const int wm0 = (wave / WARPS_N) * WM, wn0 = (wave % WARPS_N) * WN;
   // XCD-aware tile mapping (see gemm.hip)
@@ -76,50 +95,37 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_split_kernel(cons
     m0 = mt * BM;
     n0 = (lin - mt * nbx) * BN;
   }
-  const int nk = p.K / 32;
+  const int nk = p.K / (32 * KS);  // K tiles per group (host guarantees K % (32 KS) == 0)
   const int last = nk - 1;
-  const int64_t row_b = (int64_t)nk * SP_TILE_B;  // bytes per split row
+  const int64_t row_b = (int64_t)nk * (SP_TILE_B * KS);  // bytes per split row
+  constexpr int K_STEP_B = SP_TILE_B * KS;               // bytes between a group's K tiles
 
-  // ---- per-thread staging slots (fixed for the whole kernel)
-  const char* a_src[A_P];
-  const char* b_src[B_P];
-  int a_dst[A_P], b_dst[B_P];
-  unsigned a_ok = 0u, b_ok = 0u;
+  // ---- per-thread staging slots (fixed for the whole kernel).  Rows beyond M / N are
+  // loaded from a clamped (valid) address and NOT masked: an output element depends only
+  // on its own A row and B row, and rows / columns beyond the problem are never stored.
+  const char* src[L];
+  int dst[L];
 #pragma unroll
-  for (int i = 0; i < A_P; ++i) {
-    const int q = tid + NT * i, row = q / SP_PIECES, pc = q - row * SP_PIECES;
-    const bool ok = m0 + row < p.M;
-    a_src[i] = reinterpret_cast<const char*>(p.A) + (int64_t)(ok ? m0 + row : 0) * row_b + pc * 16;
-    a_dst[i] = row * SP_LDS_ROW + pc * 16;
-    if (ok) a_ok |= 1u << i;
+  for (int i = 0; i < L; ++i) {
+    int q = tid + NT * i;
+    if (q >= PIECES) q -= PIECES;
+    const int row = q / SP_PIECES, pc = q - row * SP_PIECES;  // row in [0, BM + BN)
+    const bool isA = row < BM;
+    const int grow = isA ? min(m0 + row, p.M - 1) : min(n0 + row - BM, p.N - 1);
+    src[i] = reinterpret_cast<const char*>(isA ? p.A : p.B) + (int64_t)grow * row_b + kg * SP_TILE_B + pc * 16;
+    dst[i] = row * SP_LDS_ROW + pc * 16;
   }
-#pragma unroll
-  for (int i = 0; i < B_P; ++i) {
-    const int q = tid + NT * i, row = q / SP_PIECES, pc = q - row * SP_PIECES;
-    const bool ok = n0 + row < p.N;
-    b_src[i] = reinterpret_cast<const char*>(p.B) + (int64_t)(ok ? n0 + row : 0) * row_b + pc * 16;
-    b_dst[i] = row * SP_LDS_ROW + pc * 16;
-    if (ok) b_ok |= 1u << i;
-  }
-  u32x4 ra[2][A_P], rb[2][B_P];
-  // Rows beyond M / N are loaded from a clamped (valid) address and NOT masked: an
-  // output element depends only on its own A row and B row, and rows / columns
-  // beyond the problem are never stored, so whatever they contain is harmless.
-  (void)a_ok;
-  (void)b_ok;
-  auto put_a = [&](int i, const u32x4& r, int buf) {
-    *reinterpret_cast<u32x4*>(As + buf * BM * SP_LDS_ROW + a_dst[i]) = r;
-  };
-  auto put_b = [&](int i, const u32x4& r, int buf) {
-    *reinterpret_cast<u32x4*>(Bs + buf * BN * SP_LDS_ROW + b_dst[i]) = r;
-  };
+  u32x4 rg[2][L];
+#ifdef T2H_SDBG_NOPUT
+  auto put = [&](int i, const u32x4& r, int buf) { asm volatile("" ::"v"(r), "v"(dst[i] + buf)); };
+#else
+  auto put = [&](int i, const u32x4& r, int buf) { *reinterpret_cast<u32x4*>(gsm + buf * BUF_B + dst[i]) = r; };
+#endif
   auto issue = [&](auto setc, int kt) {
     constexpr int S = decltype(setc)::value;
-    const int64_t k0 = (int64_t)min(kt, last) * SP_TILE_B;
+    const int64_t k0 = (int64_t)min(kt, last) * K_STEP_B;
 #pragma unroll
-    for (int i = 0; i < B_P; ++i) gload16_async(rb[S][i], b_src[i] + k0);
-#pragma unroll
-    for (int i = 0; i < A_P; ++i) gload16_async(ra[S][i], a_src[i] + k0);
+    for (int i = 0; i < L; ++i) gload16_async(rg[S][i], src[i] + k0);
   };
 
   f32x16 acc[TM][TN];
@@ -134,14 +140,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_split_kernel(cons
   using set1 = std::integral_constant<int, 1>;
   issue(set0{}, 0);
 #pragma unroll
-  for (int i = 0; i < B_P; ++i) {
-    wait_vmcnt16<0>(rb[0][i]);
-    put_b(i, rb[0][i], 0);
-  }
-#pragma unroll
-  for (int i = 0; i < A_P; ++i) {
-    wait_vmcnt16<0>(ra[0][i]);
-    put_a(i, ra[0][i], 0);
+  for (int i = 0; i < L; ++i) {
+    wait_vmcnt16<0>(rg[0][i]);
+    put(i, rg[0][i], 0);
   }
   __builtin_amdgcn_sched_barrier(0);
   issue(set1{}, 1);
@@ -155,9 +156,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_split_kernel(cons
   auto step = [&](int kt, auto setc) {  // register set S holds tile kt+1
     constexpr int S = decltype(setc)::value;
     const int buf = kt & 1;
-    const int64_t kn = (int64_t)min(kt + 3, last) * SP_TILE_B;
-    const char* Ab = As + buf * BM * SP_LDS_ROW + (wm0 + l31) * SP_LDS_ROW + hh * 16;
-    const char* Bb = Bs + buf * BN * SP_LDS_ROW + (wn0 + l31) * SP_LDS_ROW + hh * 16;
+    const int64_t kn = (int64_t)min(kt + 3, last) * K_STEP_B;
+    const char* Ab = gsm + buf * BUF_B + (wm0 + l31) * SP_LDS_ROW + hh * 16;
+    const char* Bb = gsm + buf * BUF_B + (BM + wn0 + l31) * SP_LDS_ROW + hh * 16;
     int mma = 0;  // running MFMA count inside the tile (compile-time after unrolling)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {  // two k16 steps per K tile
@@ -166,20 +167,32 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_split_kernel(cons
       for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
+#ifdef T2H_SDBG_NOFRAG
+          asm volatile("" : "=v"(af[ti][pl]) : "v"(Ab));
+#else
           af[ti][pl] = *reinterpret_cast<const bf16x8*>(Ab + ti * 32 * SP_LDS_ROW + pl * 64 + u * 32);
+#endif
 #pragma unroll
       for (int tj = 0; tj < TN; ++tj)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
+#ifdef T2H_SDBG_NOFRAG
+          asm volatile("" : "=v"(bfr[tj][pl]) : "v"(Bb));
+#else
           bfr[tj][pl] = *reinterpret_cast<const bf16x8*>(Bb + tj * 32 * SP_LDS_ROW + pl * 64 + u * 32);
+#endif
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
           for (int tj = 0; tj < TN; ++tj) {
+#ifdef T2H_SDBG_NOMMA
+            asm volatile("" : "+v"(acc[ti][tj]) : "v"(af[ti][PA[t]]), "v"(bfr[tj][PB[t]]));
+#else
             acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti][PA[t]], bfr[tj][PB[t]],
                                                                    acc[ti][tj], 0, 0, 0);
+#endif
             ++mma;
             // staged pieces pinned behind the MFMAs of the second half of the tile
 #pragma unroll
@@ -187,17 +200,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_split_kernel(cons
               const int at = (2 * L <= NMMA) ? NMMA - 2 * (L - q) + 1 : (NMMA * (q + 1)) / L;
               if (at != mma) continue;
               __builtin_amdgcn_sched_barrier(0);
-              if (q < B_P) {
-                wait_vmcnt16<2 * L - 1>(rb[S][q]);
-                put_b(q, rb[S][q], buf ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                gload16_async(rb[S][q], b_src[q] + kn);
-              } else {
-                wait_vmcnt16<2 * L - 1>(ra[S][q - B_P]);
-                put_a(q - B_P, ra[S][q - B_P], buf ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                gload16_async(ra[S][q - B_P], a_src[q - B_P] + kn);
-              }
+              wait_vmcnt16<2 * L - 1>(rg[S][q]);
+              put(q, rg[S][q], buf ^ 1);
+              __builtin_amdgcn_sched_barrier(0);
+              gload16_async(rg[S][q], src[q] + kn);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -212,42 +218,38 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_split_kernel(cons
   }
   if (nk & 1) step(nk - 1, set1{});
 #pragma unroll
-  for (int S = 0; S < 2; ++S) {
+  for (int S = 0; S < 2; ++S)
 #pragma unroll
-    for (int i = 0; i < B_P; ++i) wait_vmcnt16<0>(rb[S][i]);
-#pragma unroll
-    for (int i = 0; i < A_P; ++i) wait_vmcnt16<0>(ra[S][i]);
-  }
+    for (int i = 0; i < L; ++i) wait_vmcnt16<0>(rg[S][i]);
 
   // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (r&3) +
   // 8*(r>>2) + 4*(lane>>5)) are transposed through the (now idle) LDS so that every
   // lane owns 4 CONSECUTIVE columns of a row: residual loads and fp32 stores become
   // 16-byte accesses and a split-row store is three 8-byte writes instead of twelve
   // 2-byte ones.
-  constexpr int O_LD = WN + 4;  // floats per staged row (odd number of 16-B slots)
-  static_assert(64 * WARPS_M * WARPS_N * 0 + WM * O_LD * 4 * WARPS_M * WARPS_N <= 2 * (BM + BN) * SP_LDS_ROW,
-                "epilogue staging must fit in the tile buffers");
-  float* const Ot = reinterpret_cast<float*>(smem) + wave * (WM * O_LD);
+  float* const Ot = reinterpret_cast<float*>(smem) + wave * (WM * O_LD);  // group 0's staged wave tile
+  float* const Og = Ot + kg * (NWG * WM * O_LD);                           // this group's
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) {
       const int col = n0 + wn0 + tj * 32 + l31;
-      const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+      const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Ot[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = acc[ti][tj][r] + bv;
+        Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = acc[ti][tj][r] + bv;
     }
   __syncthreads();
   constexpr int CPR = WN / 4;              // float4 chunks per staged row
-  constexpr int NCH = WM * CPR / 64;       // chunks per lane
+  constexpr int NCH = WM * CPR / 64 / KS;  // chunks per lane (the K groups share the stores)
 #pragma unroll
   for (int it = 0; it < NCH; ++it) {
-    const int c = lane + 64 * it;
+    const int c = lane + 64 * (it + kg * NCH);
     const int rl = c / CPR, c4 = (c - rl * CPR) * 4;
     const int row = m0 + wm0 + rl, col = n0 + wn0 + c4;
     if (row >= p.M || col >= p.N) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c4);
+    if (KS == 2) v += *reinterpret_cast<const f32x4*>(Ot + NWG * WM * O_LD + rl * O_LD + c4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (p.epi_act == 1) v[e] = gelu_erf_s(v[e]);
@@ -281,10 +283,12 @@ __global__ void split3_kernel(const float* __restrict__ x, int ldx, uint16_t* __
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1>
 int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
+  T2H_REQUIRE(a.K % (32 * KS) == 0, "t2h_gemm_split_f32: this tile config needs K %% %d == 0", 32 * KS);
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N>), grid, dim3(64 * WARPS_M * WARPS_N), 0, s, a);
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS>), grid, dim3(64 * WARPS_M * WARPS_N * KS), 0,
+                     s, a);
   T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
   return T2H_OK;
 }
@@ -321,6 +325,10 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
   switch (cfg) {
     case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64
     case 2: return launch_split<64, 64, 2, 2>(a, s);    // 4 waves, wave tile 32x32
+    case 3: return launch_split<128, 64, 4, 2>(a, s);   // 8 waves, wave tile 32x32
+    case 4: return launch_split<128, 192, 4, 2>(a, s);  // 8 waves, wave tile 32x96
+    case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
+    case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
     default: return launch_split<128, 64, 2, 2>(a, s);  // 4 waves, wave tile 64x32
   }
 }

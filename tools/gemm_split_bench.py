@@ -26,6 +26,7 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    CFGS = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else list(range(7))
     M = B * 512
     g = torch.Generator().manual_seed(0)
     shapes = {'qkv': (M, 1536, 512), 'proj': (M, 512, 512), 'fc1': (M, 2048, 512), 'fc2': (M, 512, 2048)}
@@ -46,7 +47,7 @@ def main():
         assert torch.equal(w_s, w_s2.view_as(w_s)), 'device split != host split'
         t_split3 = timeit(lambda: ops.split3(a, out=a_s))
         line = f'{name:5s} M{m} N{n} K{k} | fp32: {t32:6.1f} us err {e32:.2e} | split3(A) {t_split3:5.1f} us |'
-        for cfg in (0, 1):
+        for cfg in CFGS:
             lib.t2h_gemm_split_force_config(cfg)
             ops.gemm_split(a_s, w_s, m, n, k, out=out, bias=bias)
             es = (out.double() - ref).abs().max().item()
