@@ -115,6 +115,14 @@ typedef struct t2h_gemm_split_args {
   int32_t M, N, K;
   int32_t ldc, ldr;
   int32_t epi_act;        /* 0 none, 1 GELU(erf), 2 ReLU */
+  /* optional "V transposed" routing for the q|k|v projection (transformer_arch.py:41-49):
+   * output columns >= vt_col0 (the value heads, vt_hd columns per head) are NOT written to
+   * C / C_split but, plus bias, as three bf16 planes to Vt[B][H][3][vt_hd][vt_T] with row
+   * index = b * vt_T + key; inside every group of 32 keys, key k sits at position
+   * 16(k>>4) + 8((k>>2)&1) + 4((k>>3)&1) + (k&3), the order in which t2h_mha_split_f32's
+   * P*V matrix instruction contracts them.  NULL = off. */
+  uint16_t* Vt;
+  int32_t vt_col0, vt_T, vt_hd;
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
@@ -127,6 +135,13 @@ int t2h_layernorm_split_f32(const float* x, const float* gamma, const float* bet
                             int32_t rows, int32_t C, float eps, void* stream);
 int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, int32_t T,
                                 int32_t n_head, void* stream);
+/* the same attention (transformer_arch.py:52-67, causal=False, head dim 64) with both
+ * matrix products as six bf16 partial products: q and k are read as split rows from qk_split
+ * ([B*T][ld_cols/32][3][32], q at columns [0, C), k at [C, 2C), C = 64 n_head -- the C_split
+ * output of the q|k|v projection) and v from the Vt planes the same projection wrote
+ * (t2h_gemm_split_args.Vt); output as fp32 rows y [B*T, C] and / or split rows y_split. */
+int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,
+                      uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, void* stream);
 
 /* ------------------------------------------------------ normalisation ------
  * LayerNorm over the last dim (eps 1e-5): transformer_arch.py:80-81,93-95,231,270 */

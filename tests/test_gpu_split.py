@@ -82,3 +82,83 @@ def test_sampler_net_split_matches_oracle_and_fp32_path():
     ea, eb = (ln(a) - ref).abs().max().item(), (ln(b) - ref).abs().max().item()
     assert ea < 1e-4 and eb < 1e-4, (ea, eb)
     assert eb < 3 * ea + 1e-6, f'split path error {eb:.2e} vs fp32 path {ea:.2e}'
+
+
+def _planes(x):
+    """three bf16 planes of an fp32 tensor, round-to-nearest-even like the device split"""
+    p0 = x.bfloat16()
+    r1 = x - p0.float()
+    p1 = r1.bfloat16()
+    p2 = (r1 - p1.float()).bfloat16()
+    return torch.stack([p0, p1, p2])
+
+
+def _pack_vt_host(v, B, T, H):
+    """fp32 v [B*T, H*64] -> Vt [B][H][3][64][T] (int16 view) in the kernel's key order"""
+    vt = v.view(B, T, H, 64).permute(0, 2, 3, 1).contiguous()          # [B, H, 64, T]
+    pl = _planes(vt).permute(1, 2, 0, 3, 4).contiguous()                # [B, H, 3, 64, T]
+    out = torch.empty_like(pl)
+    out[..., ops.vt_key_positions(T)] = pl
+    return out.view(torch.int16)
+
+
+@pytest.mark.parametrize('cfg', [0, 2, 3, 6])
+def test_gemm_split_routes_value_columns_to_transposed_planes(cfg):
+    B, T, H, C = 2, 512, 8, 512
+    M = B * T
+    a, w, bias = _rnd(M, C, seed=20) * 1.1, _rnd(3 * C, C, seed=21, scale=0.06), _rnd(3 * C, seed=22)
+    a_s, w_s = ops.split3(a.to(DEV)), ops.pack_split_rows_host(w).to(DEV)
+    lib = _lib.load()
+    lib.t2h_gemm_split_force_config(cfg)
+    try:
+        full = torch.empty(M, 3 * C, device=DEV)
+        ops.gemm_split(a_s, w_s, M, 3 * C, C, out=full, bias=bias.to(DEV))
+        qk_s = ops.split_rows_empty(M, 3 * C, DEV)
+        qk_s.zero_()
+        vt = ops.vt_empty(B, H, T, DEV)
+        ops.gemm_split(a_s, w_s, M, 3 * C, C, out_split=qk_s, bias=bias.to(DEV), vt=vt, vt_col0=2 * C, vt_T=T)
+    finally:
+        lib.t2h_gemm_split_force_config(-1)
+    full = full.cpu()
+    got_qk = _unsplit(qk_s.cpu(), M, 3 * C)
+    assert torch.equal(got_qk[:, :2 * C], full[:, :2 * C])
+    assert (got_qk[:, 2 * C:] == 0).all(), 'value columns must not be written as split rows'
+    assert torch.equal(vt.cpu(), _pack_vt_host(full[:, 2 * C:].contiguous(), B, T, H))
+
+
+def test_mha_split_matches_fp64_reference_as_well_as_the_fp32_kernel():
+    B, T, H, C = 2, 512, 8, 512
+    qkv = _rnd(B * T, 3 * C, seed=23) * 1.5
+    qkv[5, C:C + 64] *= 6.0       # a spiked key: forces the online-softmax rescale
+    q, k, v = [t.view(B, T, H, 64).transpose(1, 2).double() for t in qkv.split(C, dim=1)]
+    att = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(B * T, C)
+    y32 = ops.mha_noncausal(qkv.to(DEV), B, T, H).cpu().double()
+    qk_s = ops.split3(qkv.to(DEV))
+    vt = _pack_vt_host(qkv[:, 2 * C:].contiguous(), B, T, H).to(DEV)
+    y = torch.empty(B * T, C, device=DEV)
+    ops.mha_split(qk_s, 3 * C, vt, B, T, H, out=y)
+    ys = ops.mha_split(qk_s, 3 * C, vt, B, T, H, out_split=ops.split_rows_empty(B * T, C, DEV))
+    assert torch.equal(ys, ops.split3(y))
+    e32, es = (y32 - ref).abs().max().item(), (y.cpu().double() - ref).abs().max().item()
+    assert es < 5e-6 + 2 * e32, f'split attention error {es:.2e} vs fp32 kernel {e32:.2e}'
+
+
+def test_sampler_net_split_mha_on_and_off_agree_with_oracle():
+    from oracle import torch_ref as R
+    sd = synthetic.fill(synthetic.transformer_schema(18432, 1024, 18, 512, 4, 512, 18), seed=12)
+    P = weights.Params(DEV)
+    desc = weights.pack_transformer(P, sd, 'tf')
+    gen = torch.Generator().manual_seed(14)
+    idx = torch.randint(0, 18433, (3, 512), generator=gen)
+    seg = torch.randint(0, 1024, (3, 512), generator=gen)
+    tex = torch.randint(0, 18, (3, 512), generator=gen)
+    args = (idx.to(DEV), seg.to(DEV), tex.to(DEV))
+    a = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=False).hidden(*args).clone().cpu()
+    b = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=True).hidden(*args).clone().cpu()
+    with torch.no_grad():
+        ref = R.transformer_hidden(idx, seg, tex, sd)
+    ln = lambda t: F.layer_norm(t.view(3, 512, 512), (512, ), sd['ln_f.weight'], sd['ln_f.bias'], 1e-5)
+    ea, eb = (ln(a) - ref).abs().max().item(), (ln(b) - ref).abs().max().item()
+    assert ea < 1e-4 and eb < 1e-4, (ea, eb)
+    assert eb < 3 * ea + 1e-6, f'split attention path error {eb:.2e} vs fp32 attention {ea:.2e}'

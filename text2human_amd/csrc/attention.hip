@@ -213,6 +213,233 @@ __global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// The same attention with both products on the bf16 matrix cores as six partial
+// products of three-plane operands (see gemm_split.hip): q, k arrive as split rows
+// (C_split of the q|k|v projection), v as the transposed planes Vt that projection's
+// epilogue wrote, P is split in registers.  Structure identical to mha_kernel: 8 waves
+// = 4 x 32 queries x 2 key halves, transposed products, P never leaves registers --
+// with v_mfma_f32_32x32x16_bf16 a lane's B operand of k16-step j is the 8 keys
+// {16j + 4h + (e&3) + 8(e>>2)} = accumulator registers 8j .. 8j+7 of S^T, and Vt stores
+// the keys of every 32-group in exactly that order, so the A operand is one 16-byte read.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SK_ROW = 400;                      // K tile row in LDS: 2 x 192 B + 16 (25 slots, odd)
+constexpr int SV_ROW = 144;                      // Vt tile row in LDS: 64 keys x 2 B + 16 (9 slots, odd)
+constexpr int SK_TILE = KT * SK_ROW;             // 25600 B
+constexpr int SV_TILE = 3 * HD * SV_ROW;         // 27648 B
+constexpr int SKV_TILE = SK_TILE + SV_TILE;      // per key half
+
+template <int J>
+__device__ __forceinline__ void split8(const f32x16& x, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 a, b, c;
+    t2h_split3(x[8 * J + e], a, b, c);
+    p0[e] = a;
+    p1[e] = b;
+    p2[e] = c;
+  }
+}
+
+__global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restrict__ qk, int ld_cols,
+                                                        const uint16_t* __restrict__ vt, float* __restrict__ y,
+                                                        uint16_t* __restrict__ y_split, int T, int C, int n_head) {
+  __shared__ __attribute__((aligned(16))) char smem_raw[2 * SKV_TILE];
+  static_assert(2 * SKV_TILE >= (4 * 32 * 64 + 4 * 32 * O_LD) * 4, "LDS reuse layout");
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int qw = wave & 3, kh = wave >> 2;
+  int qt, head, b;
+  {
+    const int nqt = T / QB, total = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    qt = lin % nqt;
+    const int hb = lin / nqt;
+    head = hb % n_head;
+    b = hb / n_head;
+  }
+  const int q0 = qt * QB + qw * 32;
+  const int64_t row_b = (int64_t)(ld_cols / 32) * T2H_SPLIT_TILE_B;  // bytes per split row
+  const char* const qk_b = reinterpret_cast<const char*>(qk) + (int64_t)b * T * row_b;
+  const int q_tile0 = 2 * head, k_tile0 = C / 32 + 2 * head;  // 32-column tiles of this head's q / k
+
+  // Q fragments: k16-step kk covers d = 16 kk + 8 h .. + 7 of plane pl
+  bf16x8 qf[4][3];
+  {
+    const char* qp = qk_b + (int64_t)(q0 + l31) * row_b + q_tile0 * T2H_SPLIT_TILE_B + hh * 16;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        qf[kk][pl] = *reinterpret_cast<const bf16x8*>(qp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
+  }
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging per key half (256 threads): K tile = 64 keys x 24 pieces (thread: key s_t/4,
+  // pieces (s_t&3) + 4i), Vt tile = 192 (plane, d) rows x 8 pieces (thread: row s_t/8 + 32i,
+  // piece s_t&7): 6 + 6 16-byte pieces per thread, addresses affine in i
+  const int s_half = tid >> 8, s_t = tid & 255;
+  const int half_keys = T / 2;
+  char* const Ks_st = smem_raw + s_half * SKV_TILE;
+  char* const Vs_st = Ks_st + SK_TILE;
+  const char* const vt_b = reinterpret_cast<const char*>(vt) + ((int64_t)(b * n_head + head) * 3 * HD) * T * 2;
+  const char* const ksrc = qk_b + (int64_t)(s_half * half_keys + (s_t >> 2)) * row_b +
+                           k_tile0 * T2H_SPLIT_TILE_B + (s_t & 3) * 16;
+  const int kdst = (s_t >> 2) * SK_ROW + (s_t & 3) * 16;
+  const char* const vsrc = vt_b + ((int64_t)(s_t >> 3) * T + s_half * half_keys) * 2 + (s_t & 7) * 16;
+  const int vdst = (s_t >> 3) * SV_ROW + (s_t & 7) * 16;
+  const int64_t v_step = (int64_t)32 * T * 2;  // 32 (plane, d) rows further
+  u32x4 kreg[6], vreg[6];
+  auto load_kv = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      kreg[i] = *reinterpret_cast<const u32x4*>(ksrc + (int64_t)it * KT * row_b + i * 64);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vsrc + it * KT * 2 + i * v_step);
+    }
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      *reinterpret_cast<u32x4*>(Ks_st + kdst + i * 64) = kreg[i];
+      *reinterpret_cast<u32x4*>(Vs_st + vdst + i * 32 * SV_ROW) = vreg[i];
+    }
+  };
+
+  // partial products in increasing magnitude: (a2,b0) (a0,b2) (a1,b1) (a1,b0) (a0,b1) (a0,b0)
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+  const char* const Ks = smem_raw + kh * SKV_TILE;
+  const char* const Vs = Ks + SK_TILE;
+  const int nit = half_keys / KT;
+  load_kv(0);
+  for (int it = 0; it < nit; ++it) {
+    __syncthreads();  // previous tiles fully consumed
+    store_kv();
+    __syncthreads();
+    if (it + 1 < nit) load_kv(it + 1);
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // two 32-key sub-tiles
+      // ---- S^T = K Q^T
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      const char* kp = Ks + (ks * 32 + l31) * SK_ROW + hh * 16;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 kf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          kf[pl] = *reinterpret_cast<const bf16x8*>(kp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[kk][PB[t]], st, 0, 0, 0);
+      }
+      // ---- online softmax over this lane's 16 keys + partner half's 16 keys
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] *= 0.125f;
+      float mx = st[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);  // first tile: 0
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = fast_exp(st[r] - m_new);
+        psum += st[r];
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[dt][r] *= alpha;
+      // ---- O^T += V^T P^T ; k16-step j contracts keys {16j + 4h + (e&3) + 8(e>>2)} = registers 8j..8j+7
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bf16x8 pf[3];
+        if (j == 0) split8<0>(st, pf[0], pf[1], pf[2]);
+        else split8<1>(st, pf[0], pf[1], pf[2]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8 vf[3];
+          const char* vp = Vs + (dt * 32 + l31) * SV_ROW + (ks * 32 + 16 * j + 8 * hh) * 2;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) vf[pl] = *reinterpret_cast<const bf16x8*>(vp + pl * HD * SV_ROW);
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+            o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[t]], pf[PB[t]], o_acc[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- merge the two key halves: waves 4-7 publish (m, l, O), waves 0-3 combine
+  __syncthreads();
+  float* const Ox = smem;                // [4 waves][32 regs][64 lanes]
+  float* const Mx = smem + 4 * 32 * 64;  // borrowed from the staging area below:
+  float* const Lx = Mx + 4 * 64;         // consumed before that area is written
+  if (kh == 1) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ox[(qw * 32 + dt * 16 + r) * 64 + lane] = o_acc[dt][r];
+    Mx[qw * 64 + lane] = m_run;
+    Lx[qw * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  float inv_l = 0.f;
+  if (kh == 0) {
+    const float m2 = Mx[qw * 64 + lane], l2 = Lx[qw * 64 + lane];
+    const float m = fmaxf(m_run, m2);
+    const float a1 = expf(m_run - m), a2 = expf(m2 - m);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o_acc[dt][r] = o_acc[dt][r] * a1 + Ox[(qw * 32 + dt * 16 + r) * 64 + lane] * a2;
+    inv_l = 1.0f / (l_run * a1 + l2 * a2);
+  }
+  __syncthreads();  // Mx/Lx consumed before the staging area is overwritten
+  float* Os = smem + 4 * 32 * 64 + qw * 32 * O_LD;
+  if (kh == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        Os[l31 * O_LD + d] = o_acc[dt][r] * inv_l;
+      }
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const int64_t grow = (int64_t)b * T + q0;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c4);
+      if (y) *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c4) = v;
+      if (y_split) t2h_store_split4(y_split, grow + row, C, head * HD + c4, v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int32_t T,
@@ -240,5 +467,23 @@ extern "C" int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, 
   hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv,
                      static_cast<float*>(nullptr), T, C, n_head, y_split);
   T2H_CHECK_LAUNCH("t2h_mha_noncausal_split_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,
+                                 uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, void* stream) {
+  T2H_REQUIRE(qk_split && vt && (y || y_split), "t2h_mha_split_f32: NULL pointer");
+  T2H_REQUIRE(B > 0 && n_head > 0, "t2h_mha_split_f32: empty problem");
+  T2H_REQUIRE(T > 0 && T % QB == 0, "t2h_mha_split_f32: T=%d must be a multiple of %d", T, QB);
+  const int C = n_head * HD;
+  T2H_REQUIRE(ld_cols % 32 == 0 && ld_cols >= 2 * C, "t2h_mha_split_f32: ld_cols=%d must hold q and k (%d columns)",
+              ld_cols, 2 * C);
+  T2H_REQUIRE(t2h_aligned16(qk_split) && t2h_aligned16(vt) && (!y || t2h_aligned16(y)) &&
+                  (!y_split || t2h_aligned16(y_split)),
+              "t2h_mha_split_f32: 16-byte alignment");
+  dim3 grid((T / QB) * n_head * B), block(512);
+  hipLaunchKernelGGL(mha_split_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt, y,
+                     y_split, T, C, n_head);
+  T2H_CHECK_LAUNCH("t2h_mha_split_f32");
   return T2H_OK;
 }

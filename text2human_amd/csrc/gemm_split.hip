@@ -240,6 +240,42 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
         Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = acc[ti][tj][r] + bv;
     }
   __syncthreads();
+  if (p.Vt != nullptr && n0 >= p.vt_col0) {
+    // value heads of the q|k|v projection: transposed planes Vt[B][H][3][hd][T].  A chunk is
+    // one output column x 4 consecutive rows (= 4 consecutive keys, which stay adjacent
+    // under the key permutation); consecutive lanes take consecutive row groups, so a
+    // column's stores are contiguous 8-byte pieces per plane.
+    constexpr int RG = WM / 4;                   // row groups per staged column
+    constexpr int NCV = RG * WN / 64 / KS;       // chunks per lane
+    const int n_vh = (p.N - p.vt_col0) / p.vt_hd;
+#pragma unroll
+    for (int it = 0; it < NCV; ++it) {
+      const int c = lane + 64 * (it + kg * NCV);
+      const int cl = c / RG, r4 = (c - cl * RG) * 4;
+      const int row = m0 + wm0 + r4, col = n0 + wn0 + cl;
+      if (row >= p.M || col >= p.N) continue;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = Ot[(r4 + e) * O_LD + cl];
+        if (KS == 2) v[e] += Ot[NWG * WM * O_LD + (r4 + e) * O_LD + cl];
+      }
+      const int b = row / p.vt_T, key = row - b * p.vt_T;
+      const int cc = col - p.vt_col0, head = cc / p.vt_hd, d = cc - head * p.vt_hd;
+      const int w = key & 31;
+      const int pos = (key & ~31) + 16 * (w >> 4) + 8 * ((w >> 2) & 1) + 4 * ((w >> 3) & 1);
+      __bf16 sp[3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t2h_split3(v[e], sp[0][e], sp[1][e], sp[2][e]);
+      uint16_t* dstp = p.Vt + ((((int64_t)b * n_vh + head) * 3) * p.vt_hd + d) * p.vt_T + pos;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        t2h_bf16x4 w4 = {sp[pl][0], sp[pl][1], sp[pl][2], sp[pl][3]};
+        *reinterpret_cast<t2h_bf16x4*>(dstp + (int64_t)pl * p.vt_hd * p.vt_T) = w4;
+      }
+    }
+    return;
+  }
   constexpr int CPR = WN / 4;              // float4 chunks per staged row
   constexpr int NCH = WM * CPR / 64 / KS;  // chunks per lane (the K groups share the stores)
 #pragma unroll
@@ -286,6 +322,9 @@ __global__ void split3_kernel(const float* __restrict__ x, int ldx, uint16_t* __
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1>
 int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE(a.K % (32 * KS) == 0, "t2h_gemm_split_f32: this tile config needs K %% %d == 0", 32 * KS);
+  if (a.Vt)
+    T2H_REQUIRE(a.vt_col0 % BN == 0, "t2h_gemm_split_f32: vt_col0=%d must be a multiple of the %d-column tile",
+                a.vt_col0, BN);
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
   hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS>), grid, dim3(64 * WARPS_M * WARPS_N * KS), 0,
                      s, a);
@@ -306,7 +345,7 @@ extern "C" int t2h_gemm_split_force_config(int cfg) {
 extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream) {
   T2H_REQUIRE(args != nullptr, "t2h_gemm_split_f32: args is NULL");
   const t2h_gemm_split_args a = *args;
-  T2H_REQUIRE(a.A && a.B && (a.C || a.C_split), "t2h_gemm_split_f32: NULL operand");
+  T2H_REQUIRE(a.A && a.B && (a.C || a.C_split || a.Vt), "t2h_gemm_split_f32: NULL operand");
   T2H_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0, "t2h_gemm_split_f32: bad shape M=%d N=%d K=%d",
               a.M, a.N, a.K);
   T2H_REQUIRE(t2h_aligned16(a.A) && t2h_aligned16(a.B), "t2h_gemm_split_f32: operands must be 16-byte aligned");
@@ -314,6 +353,11 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
                   (!a.residual || (a.ldr % 4 == 0 && t2h_aligned16(a.residual))),
               "t2h_gemm_split_f32: N, ldc, ldr must be multiples of 4 and C / residual 16-byte aligned");
   if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
+  if (a.Vt)
+    T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 32 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&
+                    a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,
+                "t2h_gemm_split_f32: bad Vt routing (col0=%d T=%d hd=%d M=%d N=%d)", a.vt_col0, a.vt_T, a.vt_hd,
+                a.M, a.N);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int cfg = g_force_split_cfg;
   if (cfg < 0) {

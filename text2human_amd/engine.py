@@ -129,9 +129,12 @@ class SamplerNet:
     tail kernel.  24 x [LN, QKV GEMM, flash MHA, proj GEMM(+res), LN, fc1
     GEMM(+GELU), fc2 GEMM(+res)]."""
 
-    def __init__(self, P, desc, n_head, name='tf', fuse_ln=False, split=False):
+    def __init__(self, P, desc, n_head, name='tf', fuse_ln=False, split=False, split_mha=True):
         self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
         self.split = split
+        # split_mha (with split): attention on the bf16 matrix cores too -- the q|k|v
+        # projection writes q, k as split rows and v as transposed planes, no fp32 qkv
+        self.split_mha = split_mha
         # fuse_ln: LayerNorm folded into the GEMM operand staging + statistics from
         # the producer's epilogue.  Parity-tested, but MEASURED SLOWER at B=8 on
         # MI355X (2042 vs 1961 ms per batch: the statistics prologue/epilogue cost
@@ -147,7 +150,9 @@ class SamplerNet:
             self._buf = {key: dict(x=e(C), h=e(C), qkv=e(3 * C), y=e(C), u=e(4 * C),
                                    stats=torch.empty((M, C // 32, 2), device=dev, dtype=torch.float32),
                                    h_split=ops.split_rows_empty(M, C, dev), y_split=ops.split_rows_empty(M, C, dev),
-                                   u_split=ops.split_rows_empty(M, 4 * C, dev))}
+                                   u_split=ops.split_rows_empty(M, 4 * C, dev),
+                                   qk_split=ops.split_rows_empty(M, 3 * C, dev),
+                                   vt=ops.vt_empty(M // 512 if M % 512 == 0 else 1, self.n_head, 512, dev))}
         return self._buf[key]
 
     def hidden(self, idx, segm_tok, tex_tok):
@@ -165,11 +170,19 @@ class SamplerNet:
             # fc1's GELU epilogue -> u; the residual stream x and q|k|v stay fp32.
             M = B * T
             hs, ys, us = buf['h_split'], buf['y_split'], buf['u_split']
+            vt = buf['vt']
+            if self.split_mha and tuple(vt.shape) != (B, self.n_head, 3, C // self.n_head, T):
+                vt = buf['vt'] = ops.vt_empty(B, self.n_head, T, idx.device, C // self.n_head)
             for i in range(self.desc['n_layers']):
                 p = f'{nm}.{i}'
                 ops.layernorm_split(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs)
-                ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out=qkv, bias=P[f'{p}.qkv.b'])
-                ops.mha_noncausal_split(qkv, B, T, self.n_head, ys)
+                if self.split_mha:
+                    ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out_split=buf['qk_split'],
+                                   bias=P[f'{p}.qkv.b'], vt=vt, vt_col0=2 * C, vt_T=T, vt_hd=C // self.n_head)
+                    ops.mha_split(buf['qk_split'], 3 * C, vt, B, T, self.n_head, out_split=ys)
+                else:
+                    ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out=qkv, bias=P[f'{p}.qkv.b'])
+                    ops.mha_noncausal_split(qkv, B, T, self.n_head, ys)
                 ops.gemm_split(ys, P[f'{p}.proj.w_split'], M, C, C, out=x, bias=P[f'{p}.proj.b'], residual=x)
                 ops.layernorm_split(x, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs)
                 ops.gemm_split(hs, P[f'{p}.fc1.w_split'], M, 4 * C, C, out_split=us, bias=P[f'{p}.fc1.b'],

@@ -64,8 +64,11 @@ class BaseSampleModel():
         # T2H_SPLIT_GEMM=0 selects the exact-fp32 MFMA GEMMs for the sampler's Linears;
         # default: split-precision (3 x bf16 planes, six products) on the bf16 matrix
         # cores -- same fp32-class accuracy (tests/test_gpu_split.py), higher throughput
+        # (T2H_SPLIT_MHA=0 keeps the attention on the exact-fp32 kernel)
         split = os.environ.get('T2H_SPLIT_GEMM', '1') != '0'
-        self.sampler_fn = engine.SamplerNet(P, d_tf, self.opt['bert_n_head'], 'tf', split=split)
+        split_mha = os.environ.get('T2H_SPLIT_MHA', '1') != '0'
+        self.sampler_fn = engine.SamplerNet(P, d_tf, self.opt['bert_n_head'], 'tf', split=split,
+                                            split_mha=split_mha)
 
     # ------------------------------------------------------------ helpers
     def _texture_tokens(self, texture_mask):

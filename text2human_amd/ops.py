@@ -230,10 +230,13 @@ def pack_split_rows_host(w):
     return planes.view(torch.int16)
 
 
-def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE):
+def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE,
+               vt=None, vt_col0=0, vt_T=0, vt_hd=64):
     """C = act(A @ W^T + bias) + residual on the bf16 matrix cores at fp32-class
     accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
-    split-row form `out_split` of the result."""
+    split-row form `out_split` of the result.  With `vt` the output columns from
+    `vt_col0` on go to the transposed value planes of mha_split instead
+    (t2h_gemm_split_args.Vt)."""
     _chk_f32(out, bias, residual)
     g = _lib.GemmSplitArgs()
     g.A, g.B = a_split.data_ptr(), w_split.data_ptr()
@@ -245,6 +248,8 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     g.ldc = _rows(out) if out is not None else 0
     g.ldr = _rows(residual) if residual is not None else 0
     g.epi_act = act
+    if vt is not None:
+        g.Vt, g.vt_col0, g.vt_T, g.vt_hd = vt.data_ptr(), vt_col0, vt_T, vt_hd
     lib = _lib.load()
     if _prof is not None:
         _prof['count'] += 1
@@ -257,6 +262,28 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
             _prof['recs'].append(('gemm_split_kernel<3xbf16>', 2.0 * M * N * K, e0, e1))
             return out if out is not None else out_split
     check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
+    return out if out is not None else out_split
+
+
+def vt_empty(B, n_head, T, device, hd=64):
+    """Transposed value planes [B][H][3][hd][T] bf16 (as int16) for mha_split."""
+    return torch.empty(B, n_head, 3, hd, T, dtype=torch.int16, device=device)
+
+
+def vt_key_positions(T):
+    """Position of key k inside the Vt planes (include/t2h_hip.h, t2h_gemm_split_args.Vt)."""
+    k = torch.arange(T)
+    w = k & 31
+    return (k & ~31) + 16 * (w >> 4) + 8 * ((w >> 2) & 1) + 4 * ((w >> 3) & 1) + (w & 3)
+
+
+def mha_split(qk_split, ld_cols, vt, B, T, n_head, out=None, out_split=None):
+    """Attention with q, k read as split rows and v as transposed planes; both
+    products as six bf16 partial products (fp32-class accuracy)."""
+    _chk_f32(out)
+    check(_lib.load().t2h_mha_split_f32(_p(qk_split), ld_cols, _p(vt), _p(out) if out is not None else None,
+                                        _p(out_split) if out_split is not None else None, B, T, n_head,
+                                        _stream()), 't2h_mha_split_f32')
     return out if out is not None else out_split
 
 
