@@ -236,8 +236,8 @@ def main():
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': ('f32' if os.environ.get('T2H_SPLIT_GEMM', '1') == '0' else
-                  'f32 (sampler Linears as 3xbf16-split MFMA with fp32 accumulate: fp32-class accuracy, '
-                  'tokens bit-exact vs the fp32 oracle; everything else exact-fp32 MFMA)'),
+                  'f32 (sampler Linears + attention as 2xfp16-split MFMA, 3 partial products, fp32 accumulate: '
+                  'fp32-class accuracy, tokens bit-exact vs the fp32 oracle; everything else exact-fp32 MFMA)'),
         'data': 'synthetic',
         'config': {
             'workload': (f'sample_from_parsing.yml batch={args.batch}/GPU, {args.sample_steps} sampling '
@@ -254,11 +254,11 @@ def main():
         dom = max(prof.values(), key=lambda r: r['ms'])
         eq = dom['flops'] / (dom['ms'] * 1e-3) / 1e12  # fp32-equivalent 2*M*N*K per launch / time
         split = dom['kernel'].startswith('gemm_split')
-        # The split-precision kernel's algorithm is six bf16 x bf16 partial products per
-        # fp32 multiply on v_mfma_f32_32x32x16_bf16, so its matrix-core roofline is the
-        # dense bf16 peak and its algorithmic work 6 * 2*M*N*K; the fp32-equivalent rate
+        # The split-precision kernel's algorithm is three fp16 x fp16 partial products per
+        # fp32 multiply on v_mfma_f32_32x32x16_f16, so its matrix-core roofline is the
+        # dense 16-bit peak and its algorithmic work 3 * 2*M*N*K; the fp32-equivalent rate
         # and its ratio to the fp32-MFMA peak are reported next to it.
-        mult, peak = (6.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
         ach = eq * mult
         out['roofline'] = {
             'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': peak,

@@ -99,17 +99,18 @@ int t2h_gemm_tile_config(const t2h_gemm_args* args);
 int t2h_gemm_force_config(int cfg);
 
 /* ------------------------------------------------- split-precision GEMM -----
- * Same contraction on the bf16 matrix cores at fp32-class accuracy: every fp32
- * operand is carried as three bf16 planes (x = x0 + x1 + x2) and a product is the
- * six partial products of order >= 2^-18 (v_mfma_f32_32x32x16_bf16, fp32
- * accumulate).  Operands are "split rows": [rows][K/32][3][32] bf16 (192 B per
- * row and 32-wide K tile), written by t2h_split3_f32 / the C_split epilogue.
+ * Same contraction on the fp16 matrix cores at fp32-class accuracy: every fp32
+ * operand is carried as two fp16 planes (x = h + l / 2048, h = fp16(x),
+ * l = fp16((x - h) * 2048); |x| < 65504) and a product is the three partial products
+ * hh + (hl + lh) / 2048 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Operands are
+ * "split rows": [rows][K/32][2][32] fp16 (128 B per row and 32-wide K tile), written
+ * by t2h_split_rows_f32 / the C_split epilogue.
  * Replaces the same nn.Linear call sites as t2h_gemm_f32 (opt-in fast path). */
 typedef struct t2h_gemm_split_args {
-  const uint16_t* A;      /* split rows [M][K/32][3][32] */
-  const uint16_t* B;      /* split rows [N][K/32][3][32] (weights, repacked once) */
+  const uint16_t* A;      /* split rows [M][K/32][2][32] */
+  const uint16_t* B;      /* split rows [N][K/32][2][32] (weights, repacked once) */
   float* C;               /* fp32 output [M,N] ldc, or NULL */
-  uint16_t* C_split;      /* split-row output [M][N/32][3][32], or NULL */
+  uint16_t* C_split;      /* split-row output [M][N/32][2][32], or NULL */
   const float* bias;      /* [N] or NULL */
   const float* residual;  /* fp32 [M,N] ldr or NULL (added after the activation) */
   int32_t M, N, K;
@@ -117,7 +118,7 @@ typedef struct t2h_gemm_split_args {
   int32_t epi_act;        /* 0 none, 1 GELU(erf), 2 ReLU */
   /* optional "V transposed" routing for the q|k|v projection (transformer_arch.py:41-49):
    * output columns >= vt_col0 (the value heads, vt_hd columns per head) are NOT written to
-   * C / C_split but, plus bias, as three bf16 planes to Vt[B][H][3][vt_hd][vt_T] with row
+   * C / C_split but, plus bias, as the two fp16 planes to Vt[B][H][2][vt_hd][vt_T] with row
    * index = b * vt_T + key; inside every group of 32 keys, key k sits at position
    * 16(k>>4) + 8((k>>2)&1) + 4((k>>3)&1) + (k&3), the order in which t2h_mha_split_f32's
    * P*V matrix instruction contracts them.  NULL = off. */
@@ -128,7 +129,7 @@ typedef struct t2h_gemm_split_args {
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
 int t2h_gemm_split_force_config(int cfg); /* tuning: 0 128x64/4 waves, 1 128x128/8 waves, -1 auto */
 /* fp32 [rows, C] (row stride ldx) -> split rows */
-int t2h_split3_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);
+int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);
 /* producers that emit split rows directly: LayerNorm (transformer_arch.py:93-95)
  * and the attention output (transformer_arch.py:65-67) */
 int t2h_layernorm_split_f32(const float* x, const float* gamma, const float* beta, uint16_t* y_split,
@@ -136,8 +137,8 @@ int t2h_layernorm_split_f32(const float* x, const float* gamma, const float* bet
 int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, int32_t T,
                                 int32_t n_head, void* stream);
 /* the same attention (transformer_arch.py:52-67, causal=False, head dim 64) with both
- * matrix products as six bf16 partial products: q and k are read as split rows from qk_split
- * ([B*T][ld_cols/32][3][32], q at columns [0, C), k at [C, 2C), C = 64 n_head -- the C_split
+ * matrix products as three fp16 partial products: q and k are read as split rows from qk_split
+ * ([B*T][ld_cols/32][2][32], q at columns [0, C), k at [C, 2C), C = 64 n_head -- the C_split
  * output of the q|k|v projection) and v from the Vt planes the same projection wrote
  * (t2h_gemm_split_args.Vt); output as fp32 rows y [B*T, C] and / or split rows y_split. */
 int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,

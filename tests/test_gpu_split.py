@@ -1,6 +1,7 @@
-"""Split-precision path (-m gpu): three-bf16-plane operands, six-product GEMM on
-the bf16 matrix cores, split-row producers.  Accuracy bar = the exact-fp32 path's
-(summation-order-level error against an fp64 reference)."""
+"""Split-precision path (-m gpu): two-fp16-plane operands (x = h + l / 2048),
+three-product GEMM / attention on the fp16 matrix cores, split-row producers.
+Accuracy bar = the exact-fp32 path's (summation-order-level error against an fp64
+reference)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -16,18 +17,20 @@ def _rnd(*shape, seed=0, scale=1.0):
 
 
 def _unsplit(s, rows, c):
-    return s.view(torch.bfloat16).view(rows, c // 32, 3, 32).float().sum(2).reshape(rows, c)
+    return ops.unsplit_rows_host(s, rows, c)
 
 
-def test_split3_is_exact_to_fp32_and_matches_host_pack():
-    x = torch.cat([_rnd(300, 512, seed=1) * 3, _rnd(300, 512, seed=2) * 1e-3, _rnd(8, 512, seed=3) * 1e4])
-    s = ops.split3(x.to(DEV))
+def test_split_rows_carry_22_bits_and_match_the_host_pack():
+    x = torch.cat([_rnd(300, 512, seed=1) * 3, _rnd(300, 512, seed=2) * 1e-3, _rnd(8, 512, seed=3) * 1e4,
+                   _rnd(8, 512, seed=4) * 1e-6])
+    s = ops.split_rows(x.to(DEV))
     assert torch.equal(s.cpu(), ops.pack_split_rows_host(x).view_as(s.cpu()))
     back = _unsplit(s.cpu(), x.shape[0], 512)
-    assert ((back - x).abs() <= x.abs() * 2.0**-23).all()
+    # two 11-bit planes; below 2^-14 the hi plane is subnormal and the bound is absolute
+    assert ((back - x).abs() <= x.abs() * 2.0**-21 + 2.0**-36).all()
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 5, 6])
 @pytest.mark.parametrize('M,N,K', [(4096, 512, 512), (1024, 1536, 512), (512, 512, 2048), (130, 96, 64),
                                    (40, 32, 32)])
 def test_gemm_split(cfg, M, N, K):
@@ -35,7 +38,7 @@ def test_gemm_split(cfg, M, N, K):
         pytest.skip('the in-block K split needs K % 64 == 0')
     a, w, b, r = _rnd(M, K, seed=4) * 1.3, _rnd(N, K, seed=5, scale=0.08), _rnd(N, seed=6), _rnd(M, N, seed=7)
     ref = a.double() @ w.double().t() + b.double()
-    a_s, w_s = ops.split3(a.to(DEV)), ops.pack_split_rows_host(w).to(DEV)
+    a_s, w_s = ops.split_rows(a.to(DEV)), ops.pack_split_rows_host(w).to(DEV)
     lib = _lib.load()
     lib.t2h_gemm_split_force_config(cfg)
     try:
@@ -57,11 +60,11 @@ def test_split_producers_are_bitwise_the_split_of_the_fp32_result():
     x, g, b = _rnd(777, 512, seed=8) * 2 + 0.1, _rnd(512, seed=9) * 0.1 + 1, _rnd(512, seed=10) * 0.1
     ln = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
     ln_s = ops.layernorm_split(x.to(DEV), g.to(DEV), b.to(DEV), ops.split_rows_empty(777, 512, DEV))
-    assert torch.equal(ln_s, ops.split3(ln))
+    assert torch.equal(ln_s, ops.split_rows(ln))
     qkv = (_rnd(2 * 512, 1536, seed=11) * 1.2).to(DEV)
     y = ops.mha_noncausal(qkv, 2, 512, 8)
     y_s = ops.mha_noncausal_split(qkv, 2, 512, 8, ops.split_rows_empty(1024, 512, DEV))
-    assert torch.equal(y_s, ops.split3(y))
+    assert torch.equal(y_s, ops.split_rows(y))
 
 
 def test_sampler_net_split_matches_oracle_and_fp32_path():
@@ -84,19 +87,10 @@ def test_sampler_net_split_matches_oracle_and_fp32_path():
     assert eb < 3 * ea + 1e-6, f'split path error {eb:.2e} vs fp32 path {ea:.2e}'
 
 
-def _planes(x):
-    """three bf16 planes of an fp32 tensor, round-to-nearest-even like the device split"""
-    p0 = x.bfloat16()
-    r1 = x - p0.float()
-    p1 = r1.bfloat16()
-    p2 = (r1 - p1.float()).bfloat16()
-    return torch.stack([p0, p1, p2])
-
-
 def _pack_vt_host(v, B, T, H):
-    """fp32 v [B*T, H*64] -> Vt [B][H][3][64][T] (int16 view) in the kernel's key order"""
+    """fp32 v [B*T, H*64] -> Vt [B][H][2][64][T] (int16 view) in the kernel's key order"""
     vt = v.view(B, T, H, 64).permute(0, 2, 3, 1).contiguous()          # [B, H, 64, T]
-    pl = _planes(vt).permute(1, 2, 0, 3, 4).contiguous()                # [B, H, 3, 64, T]
+    pl = torch.stack(ops.split_planes_host(vt)).permute(1, 2, 0, 3, 4).contiguous()  # [B, H, 2, 64, T]
     out = torch.empty_like(pl)
     out[..., ops.vt_key_positions(T)] = pl
     return out.view(torch.int16)
@@ -107,7 +101,7 @@ def test_gemm_split_routes_value_columns_to_transposed_planes(cfg):
     B, T, H, C = 2, 512, 8, 512
     M = B * T
     a, w, bias = _rnd(M, C, seed=20) * 1.1, _rnd(3 * C, C, seed=21, scale=0.06), _rnd(3 * C, seed=22)
-    a_s, w_s = ops.split3(a.to(DEV)), ops.pack_split_rows_host(w).to(DEV)
+    a_s, w_s = ops.split_rows(a.to(DEV)), ops.pack_split_rows_host(w).to(DEV)
     lib = _lib.load()
     lib.t2h_gemm_split_force_config(cfg)
     try:
@@ -120,9 +114,10 @@ def test_gemm_split_routes_value_columns_to_transposed_planes(cfg):
     finally:
         lib.t2h_gemm_split_force_config(-1)
     full = full.cpu()
-    got_qk = _unsplit(qk_s.cpu(), M, 3 * C)
-    assert torch.equal(got_qk[:, :2 * C], full[:, :2 * C])
-    assert (got_qk[:, 2 * C:] == 0).all(), 'value columns must not be written as split rows'
+    want = ops.pack_split_rows_host(full)                      # [M, 3C/32, 2, 32]
+    got = qk_s.cpu()
+    assert torch.equal(got[:, :2 * C // 32], want[:, :2 * C // 32])
+    assert (got[:, 2 * C // 32:] == 0).all(), 'value columns must not be written as split rows'
     assert torch.equal(vt.cpu(), _pack_vt_host(full[:, 2 * C:].contiguous(), B, T, H))
 
 
@@ -134,12 +129,12 @@ def test_mha_split_matches_fp64_reference_as_well_as_the_fp32_kernel():
     att = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
     ref = (att @ v).transpose(1, 2).reshape(B * T, C)
     y32 = ops.mha_noncausal(qkv.to(DEV), B, T, H).cpu().double()
-    qk_s = ops.split3(qkv.to(DEV))
+    qk_s = ops.split_rows(qkv.to(DEV))
     vt = _pack_vt_host(qkv[:, 2 * C:].contiguous(), B, T, H).to(DEV)
     y = torch.empty(B * T, C, device=DEV)
     ops.mha_split(qk_s, 3 * C, vt, B, T, H, out=y)
     ys = ops.mha_split(qk_s, 3 * C, vt, B, T, H, out_split=ops.split_rows_empty(B * T, C, DEV))
-    assert torch.equal(ys, ops.split3(y))
+    assert torch.equal(ys, ops.split_rows(y))
     e32, es = (y32 - ref).abs().max().item(), (y.cpu().double() - ref).abs().max().item()
     assert es < 5e-6 + 2 * e32, f'split attention error {es:.2e} vs fp32 kernel {e32:.2e}'
 
@@ -156,6 +151,9 @@ def test_sampler_net_split_mha_on_and_off_agree_with_oracle():
     args = (idx.to(DEV), seg.to(DEV), tex.to(DEV))
     a = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=False).hidden(*args).clone().cpu()
     b = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=True).hidden(*args).clone().cpu()
+    # batch slices on separate streams run the same kernels on the same rows
+    c = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=True, n_streams=3).hidden(*args).clone().cpu()
+    assert torch.equal(b, c)
     with torch.no_grad():
         ref = R.transformer_hidden(idx, seg, tex, sd)
     ln = lambda t: F.layer_norm(t.view(3, 512, 512), (512, ), sd['ln_f.weight'], sd['ln_f.bias'], 1e-5)

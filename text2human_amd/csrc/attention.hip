@@ -215,43 +215,69 @@ __global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
 
 
 // ---------------------------------------------------------------------------------
-// The same attention with both products on the bf16 matrix cores as six partial
-// products of three-plane operands (see gemm_split.hip): q, k arrive as split rows
+// The same attention with both products on the 16-bit matrix cores as three partial
+// products of two-plane fp16 operands (see gemm_split.hip): q, k arrive as split rows
 // (C_split of the q|k|v projection), v as the transposed planes Vt that projection's
 // epilogue wrote, P is split in registers.  Structure identical to mha_kernel: 8 waves
 // = 4 x 32 queries x 2 key halves, transposed products, P never leaves registers --
-// with v_mfma_f32_32x32x16_bf16 a lane's B operand of k16-step j is the 8 keys
+// with v_mfma_f32_32x32x16_f16 a lane's B operand of k16-step j is the 8 keys
 // {16j + 4h + (e&3) + 8(e>>2)} = accumulator registers 8j .. 8j+7 of S^T, and Vt stores
 // the keys of every 32-group in exactly that order, so the A operand is one 16-byte read.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef t2h_f16x8 f16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SK_ROW = 400;                      // K tile row in LDS: 2 x 192 B + 16 (25 slots, odd)
+constexpr int SK_ROW = 272;                      // K tile row in LDS: 2 x 128 B + 16 (17 slots, odd)
 constexpr int SV_ROW = 144;                      // Vt tile row in LDS: 64 keys x 2 B + 16 (9 slots, odd)
-constexpr int SK_TILE = KT * SK_ROW;             // 25600 B
-constexpr int SV_TILE = 3 * HD * SV_ROW;         // 27648 B
+constexpr int SK_TILE = KT * SK_ROW;             // 17408 B
+constexpr int SV_TILE = 2 * HD * SV_ROW;         // 18432 B
 constexpr int SKV_TILE = SK_TILE + SV_TILE;      // per key half
 
 template <int J>
-__device__ __forceinline__ void split8(const f32x16& x, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+__device__ __forceinline__ void split8(const f32x16& x, f16x8& hi, f16x8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    __bf16 a, b, c;
-    t2h_split3(x[8 * J + e], a, b, c);
-    p0[e] = a;
-    p1[e] = b;
-    p2[e] = c;
+    _Float16 a, b;
+    t2h_split2(x[8 * J + e], a, b);
+    hi[e] = a;
+    lo[e] = b;
   }
+}
+
+#ifdef T2H_MHA_TIMING
+__device__ long long* g_mha_timing = nullptr;  // debug builds only (tools/mha_split_ablate.py)
+#define TM_NOW() clock64()
+#else
+#define TM_NOW() 0ll
+#endif
+
+// Barrier among the 4 waves of ONE key half (monotonic LDS counter).  The two key halves
+// share nothing until the final merge; a block-wide barrier per K/V tile would keep the
+// two waves of a SIMD (same queries, different key half) in lockstep -- both in their
+// matrix phase, then both in their softmax phase -- whereas independent halves, started
+// half a tile apart, run one wave's exp / split VALU work under the other's MFMAs.
+__device__ __forceinline__ void half_barrier(int* ctr, int target, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads / writes are done
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+    __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
 }
 
 __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restrict__ qk, int ld_cols,
                                                         const uint16_t* __restrict__ vt, float* __restrict__ y,
                                                         uint16_t* __restrict__ y_split, int T, int C, int n_head) {
-  __shared__ __attribute__((aligned(16))) char smem_raw[2 * SKV_TILE];
-  static_assert(2 * SKV_TILE >= (4 * 32 * 64 + 4 * 32 * O_LD) * 4, "LDS reuse layout");
+  // two (K, Vt) tile pairs; reused at the end for the merge + output transpose staging
+  constexpr int SMEM_B = 2 * SKV_TILE > (4 * 32 * 64 + 4 * 32 * O_LD) * 4 ? 2 * SKV_TILE
+                                                                           : (4 * 32 * 64 + 4 * 32 * O_LD) * 4;
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_B + 16];
   float* const smem = reinterpret_cast<float*>(smem_raw);
+  int* const bar = reinterpret_cast<int*>(smem_raw + SMEM_B);  // one counter per key half
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long tm0 = TM_NOW();
+  long long tm_stage = 0, tm_comp = 0;
+  if (tid < 2) bar[tid] = 0;
+  __syncthreads();
   const int l31 = lane & 31, hh = lane >> 5;
   const int qw = wave & 3, kh = wave >> 2;
   int qt, head, b;
@@ -270,87 +296,101 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   const int q_tile0 = 2 * head, k_tile0 = C / 32 + 2 * head;  // 32-column tiles of this head's q / k
 
   // Q fragments: k16-step kk covers d = 16 kk + 8 h .. + 7 of plane pl
-  bf16x8 qf[4][3];
+  f16x8 qf[4][2];
   {
     const char* qp = qk_b + (int64_t)(q0 + l31) * row_b + q_tile0 * T2H_SPLIT_TILE_B + hh * 16;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        qf[kk][pl] = *reinterpret_cast<const bf16x8*>(qp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
+      for (int pl = 0; pl < 2; ++pl)
+        qf[kk][pl] = *reinterpret_cast<const f16x8*>(qp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
   }
 
-  f32x16 o_acc[2];
+  f32x16 o_acc[2], o_lo[2];  // O^T = o_acc + 2^-11 o_lo (hi*hi and the cross products)
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) o_acc[dt][r] = o_lo[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // staging per key half (256 threads): K tile = 64 keys x 24 pieces (thread: key s_t/4,
-  // pieces (s_t&3) + 4i), Vt tile = 192 (plane, d) rows x 8 pieces (thread: row s_t/8 + 32i,
-  // piece s_t&7): 6 + 6 16-byte pieces per thread, addresses affine in i
+  // staging per key half (256 threads): K tile = 64 keys x 16 pieces (thread: key s_t/4,
+  // pieces (s_t&3) + 4i), Vt tile = 128 (plane, d) rows x 8 pieces (thread: row s_t/8 + 32i,
+  // piece s_t&7): 4 + 4 16-byte pieces per thread, addresses affine in i
   const int s_half = tid >> 8, s_t = tid & 255;
   const int half_keys = T / 2;
   char* const Ks_st = smem_raw + s_half * SKV_TILE;
   char* const Vs_st = Ks_st + SK_TILE;
-  const char* const vt_b = reinterpret_cast<const char*>(vt) + ((int64_t)(b * n_head + head) * 3 * HD) * T * 2;
+  const char* const vt_b = reinterpret_cast<const char*>(vt) + ((int64_t)(b * n_head + head) * 2 * HD) * T * 2;
   const char* const ksrc = qk_b + (int64_t)(s_half * half_keys + (s_t >> 2)) * row_b +
                            k_tile0 * T2H_SPLIT_TILE_B + (s_t & 3) * 16;
   const int kdst = (s_t >> 2) * SK_ROW + (s_t & 3) * 16;
   const char* const vsrc = vt_b + ((int64_t)(s_t >> 3) * T + s_half * half_keys) * 2 + (s_t & 7) * 16;
   const int vdst = (s_t >> 3) * SV_ROW + (s_t & 7) * 16;
   const int64_t v_step = (int64_t)32 * T * 2;  // 32 (plane, d) rows further
-  u32x4 kreg[6], vreg[6];
+  u32x4 kreg[4], vreg[4];
   auto load_kv = [&](int it) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 4; ++i) {
       kreg[i] = *reinterpret_cast<const u32x4*>(ksrc + (int64_t)it * KT * row_b + i * 64);
       vreg[i] = *reinterpret_cast<const u32x4*>(vsrc + it * KT * 2 + i * v_step);
     }
   };
   auto store_kv = [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<u32x4*>(Ks_st + kdst + i * 64) = kreg[i];
       *reinterpret_cast<u32x4*>(Vs_st + vdst + i * 32 * SV_ROW) = vreg[i];
     }
   };
 
-  // partial products in increasing magnitude: (a2,b0) (a0,b2) (a1,b1) (a1,b0) (a0,b1) (a0,b0)
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  // partial products (A plane, B plane): (l,h) (h,l) -> the 2^-11 accumulator, (h,h) -> the main one
+  constexpr int PA[3] = {1, 0, 0};
+  constexpr int PB[3] = {0, 1, 0};
 
   const char* const Ks = smem_raw + kh * SKV_TILE;
   const char* const Vs = Ks + SK_TILE;
   const int nit = half_keys / KT;
   load_kv(0);
+  // staging threads [0,256) are waves 0-3 = key half 0, [256,512) waves 4-7 = half 1, so a
+  // half stages exactly the tiles its own waves read (s_half == kh)
+  int bar_n = 0;
+  if (kh == 1) __builtin_amdgcn_s_sleep(24);  // ~1.5k cycles: start the halves out of phase
+  const long long tm1 = TM_NOW();
   for (int it = 0; it < nit; ++it) {
-    __syncthreads();  // previous tiles fully consumed
+    const long long ta = TM_NOW();
+#ifndef T2H_MDBG_NOSTAGE
+    half_barrier(bar + kh, bar_n += 4, lane);  // previous tile fully consumed by this half
     store_kv();
-    __syncthreads();
+    half_barrier(bar + kh, bar_n += 4, lane);
     if (it + 1 < nit) load_kv(it + 1);
+#endif
+    const long long tb = TM_NOW();
+    tm_stage += tb - ta;
 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {  // two 32-key sub-tiles
       // ---- S^T = K Q^T
-      f32x16 st;
+      f32x16 st, st_lo;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      for (int r = 0; r < 16; ++r) st[r] = st_lo[r] = 0.f;
       const char* kp = Ks + (ks * 32 + l31) * SK_ROW + hh * 16;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 kf[3];
+        f16x8 kf[2];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          kf[pl] = *reinterpret_cast<const bf16x8*>(kp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[kk][PB[t]], st, 0, 0, 0);
+        for (int pl = 0; pl < 2; ++pl)
+          kf[pl] = *reinterpret_cast<const f16x8*>(kp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
+#ifdef T2H_MDBG_NOMMA
+        asm volatile("" : "+v"(st), "+v"(st_lo) : "v"(kf[0]), "v"(kf[1]), "v"(qf[kk][0]), "v"(qf[kk][1]));
+#else
+        st_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[0]], qf[kk][PB[0]], st_lo, 0, 0, 0);
+        st_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[1]], qf[kk][PB[1]], st_lo, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[2]], qf[kk][PB[2]], st, 0, 0, 0);
+#endif
       }
       // ---- online softmax over this lane's 16 keys + partner half's 16 keys
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] *= 0.125f;
+      for (int r = 0; r < 16; ++r) st[r] = fmaf(st_lo[r], T2H_SPLIT_LO_INV, st[r]) * 0.125f;
       float mx = st[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
@@ -360,7 +400,11 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifdef T2H_MDBG_NOEXP
+        st[r] = st[r] - m_new;
+#else
         st[r] = fast_exp(st[r] - m_new);
+#endif
         psum += st[r];
       }
       psum += __shfl_xor(psum, 32, 64);
@@ -369,28 +413,46 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) {
+          o_acc[dt][r] *= alpha;
+          o_lo[dt][r] *= alpha;
+        }
       // ---- O^T += V^T P^T ; k16-step j contracts keys {16j + 4h + (e&3) + 8(e>>2)} = registers 8j..8j+7
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        bf16x8 pf[3];
-        if (j == 0) split8<0>(st, pf[0], pf[1], pf[2]);
-        else split8<1>(st, pf[0], pf[1], pf[2]);
+        f16x8 pf[2];
+#ifdef T2H_MDBG_NOSPLIT
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[0][e] = pf[1][e] = (_Float16)st[8 * j + e];
+#else
+        if (j == 0) split8<0>(st, pf[0], pf[1]);
+        else split8<1>(st, pf[0], pf[1]);
+#endif
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          bf16x8 vf[3];
+          f16x8 vf[2];
           const char* vp = Vs + (dt * 32 + l31) * SV_ROW + (ks * 32 + 16 * j + 8 * hh) * 2;
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) vf[pl] = *reinterpret_cast<const bf16x8*>(vp + pl * HD * SV_ROW);
-#pragma unroll
-          for (int t = 0; t < 6; ++t)
-            o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[t]], pf[PB[t]], o_acc[dt], 0, 0, 0);
+          for (int pl = 0; pl < 2; ++pl) vf[pl] = *reinterpret_cast<const f16x8*>(vp + pl * HD * SV_ROW);
+#ifdef T2H_MDBG_NOMMA
+          asm volatile("" : "+v"(o_acc[dt]), "+v"(o_lo[dt]) : "v"(vf[0]), "v"(vf[1]), "v"(pf[0]), "v"(pf[1]));
+#else
+          o_lo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[PA[0]], pf[PB[0]], o_lo[dt], 0, 0, 0);
+          o_lo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[PA[1]], pf[PB[1]], o_lo[dt], 0, 0, 0);
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[PA[2]], pf[PB[2]], o_acc[dt], 0, 0, 0);
+#endif
         }
       }
     }
+    tm_comp += TM_NOW() - tb;
   }
 
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[dt][r] = fmaf(o_lo[dt][r], T2H_SPLIT_LO_INV, o_acc[dt][r]);
   // ---- merge the two key halves: waves 4-7 publish (m, l, O), waves 0-3 combine
+  const long long tm2 = TM_NOW();
   __syncthreads();
   float* const Ox = smem;                // [4 waves][32 regs][64 lanes]
   float* const Mx = smem + 4 * 32 * 64;  // borrowed from the staging area below:
@@ -438,6 +500,13 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
       if (y_split) t2h_store_split4(y_split, grow + row, C, head * HD + c4, v);
     }
   }
+#ifdef T2H_MHA_TIMING
+  if (g_mha_timing && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4)) {
+    long long* o = g_mha_timing + (wave == 4 ? 8 : 0);
+    const long long te = clock64();
+    o[0] = te - tm0; o[1] = tm1 - tm0; o[2] = tm_stage; o[3] = tm_comp; o[4] = te - tm2; o[5] = tm2 - tm1;
+  }
+#endif
 }
 
 }  // namespace
@@ -487,3 +556,9 @@ extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, cons
   T2H_CHECK_LAUNCH("t2h_mha_split_f32");
   return T2H_OK;
 }
+
+#ifdef T2H_MHA_TIMING
+extern "C" int t2h_debug_set_mha_timing_buffer(void* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mha_timing), &dev_ptr, sizeof(void*));
+}
+#endif

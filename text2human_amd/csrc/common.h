@@ -62,28 +62,35 @@ __device__ __forceinline__ float fast_exp(float x) {
   return fmaf(r, e * 0.693147180559945309417f, r);
 }
 
-// ---- split-row (3 x bf16 planes) helpers shared by the producers of
-// t2h_gemm_split_f32 operands: x = p0 + p1 + p2, layout [rows][C/32][3][32] bf16
-constexpr int T2H_SPLIT_TILE_B = 192;  // bytes per (row, 32-column tile)
-typedef __bf16 t2h_bf16x4 __attribute__((ext_vector_type(4)));
+// ---- split-row helpers shared by the producers of t2h_gemm_split_f32 operands.
+// An fp32 value is carried as two fp16 planes, x = h + l * 2^-11 with h = fp16(x) and
+// l = fp16((x - h) * 2^11) (22 significant bits; the 2^11 keeps the residual out of
+// fp16's subnormal range).  Layout [rows][C/32][2 planes][32] fp16 = 128 bytes -- one
+// cache line -- per (row, 32-column tile).  Operands must satisfy |x| < 65504.
+constexpr int T2H_SPLIT_TILE_B = 128;        // bytes per (row, 32-column tile)
+constexpr int T2H_SPLIT_PLANE_B = 64;        // bytes per plane inside a tile
+constexpr float T2H_SPLIT_LO_SCALE = 2048.0f;
+constexpr float T2H_SPLIT_LO_INV = 1.0f / 2048.0f;
+typedef _Float16 t2h_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 t2h_f16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void t2h_split3(float x, __bf16& p0, __bf16& p1, __bf16& p2) {
-  p0 = (__bf16)x;
-  const float r1 = x - (float)p0;
-  p1 = (__bf16)r1;
-  p2 = (__bf16)(r1 - (float)p1);
+__device__ __forceinline__ void t2h_split2(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * T2H_SPLIT_LO_SCALE);
 }
 
 // writes 4 consecutive columns c0..c0+3 (c0 % 4 == 0) of `row` as split rows
 __device__ __forceinline__ void t2h_store_split4(uint16_t* base, int64_t row, int C, int c0, f32x4 v) {
-  __bf16 s[3][4];
+  t2h_f16x4 h, l;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) t2h_split3(v[e], s[0][e], s[1][e], s[2][e]);
+  for (int e = 0; e < 4; ++e) {
+    _Float16 a, b;
+    t2h_split2(v[e], a, b);
+    h[e] = a;
+    l[e] = b;
+  }
   char* d = reinterpret_cast<char*>(base) + row * (int64_t)(C / 32) * T2H_SPLIT_TILE_B +
             (c0 >> 5) * T2H_SPLIT_TILE_B + (c0 & 31) * 2;
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    t2h_bf16x4 w = {s[pl][0], s[pl][1], s[pl][2], s[pl][3]};
-    *reinterpret_cast<t2h_bf16x4*>(d + pl * 64) = w;
-  }
+  *reinterpret_cast<t2h_f16x4*>(d) = h;
+  *reinterpret_cast<t2h_f16x4*>(d + T2H_SPLIT_PLANE_B) = l;
 }

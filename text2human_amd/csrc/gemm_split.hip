@@ -1,24 +1,28 @@
-// fp32-accurate GEMM on the bf16 matrix cores ("3xbf16 split", 6 products).
+// fp32-accurate GEMM on the 16-bit matrix cores ("2 x fp16 split", 3 products).
 //
 //   C[M,N] = epi(A[M,K] * B[N,K]^T + bias) + residual
 //
-// Every fp32 operand x is carried as three bf16 planes x = x0 + x1 + x2
-// (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 3 x 8 = 24 mantissa
-// bits, i.e. the fp32 value itself up to 2^-25 relative).  A product a*b is
-// evaluated as the six partial products whose order is >= 2^-18
-//   a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0          (dropped: a1b2, a2b1, a2b2 <= 2^-26)
-// each an exact bf16 x bf16 product accumulated in fp32 by
-// v_mfma_f32_32x32x16_bf16.  Six MFMAs at 16x the fp32-MFMA rate = 2.67x the
-// matrix throughput of v_mfma_f32_32x32x2_f32 at fp32-class accuracy.
+// Every fp32 operand x is carried as two fp16 planes, x = h + l * 2^-11 with
+// h = fp16(x), l = fp16((x - h) * 2^11): 22 significant bits, the scaling keeps the
+// residual plane out of fp16's subnormal range (cf. Ootomo & Yokota's error-corrected
+// tensor-core GEMM, the same idea as 3xTF32).  A product a*b is evaluated as
+//   ah*bh  +  2^-11 (ah*bl + al*bh)                       (dropped: al*bl <= 2^-22)
+// each an exact fp16 x fp16 product accumulated in fp32 by v_mfma_f32_32x32x16_f16,
+// the 2^-11 terms in their own accumulator that is folded in once in the epilogue.
+// The representation error (2^-22 per term, random sign) is an order of magnitude
+// below the fp32 accumulation error of a K >= 512 dot product, so the result is as
+// close to the fp64 product as the exact-fp32 kernel's (tests/test_gpu_split.py).
+// Three MFMAs at 16x the fp32-MFMA rate = 5.3x the matrix throughput of
+// v_mfma_f32_32x32x2_f32.
 //
-// Operand layout in HBM ("split rows"): [rows][K/32][3 planes][32 k] bf16, i.e. 192
-// contiguous bytes per (row, 32-wide K tile): the producers (LayerNorm, GELU /
-// attention epilogues, the weight repacker) write it directly, and a K tile of a
-// row is staged global -> LDS as twelve 16-byte pieces without any conversion.
-// LDS rows are padded to 208 B (13 slots of 16 B, odd) so the per-lane 16-byte
-// fragment reads (ds_read_b128, 8 consecutive k of one plane) are conflict free.
-// Main loop = the same two-register-set, counted-vmcnt software pipeline as the
-// fp32 kernel (gemm.hip): staged pieces are written to LDS and re-issued in the
+// Operand layout in HBM ("split rows"): [rows][K/32][2 planes][32 k] fp16, i.e. 128
+// contiguous bytes (one cache line) per (row, 32-wide K tile): the producers
+// (LayerNorm, GELU / attention epilogues, the weight repacker) write it directly, and
+// a K tile of a row is staged global -> LDS as eight 16-byte pieces without any
+// conversion.  LDS rows are padded to 144 B (9 slots of 16 B, odd) so the per-lane
+// 16-byte fragment reads (ds_read_b128, 8 consecutive k of one plane) are conflict
+// free.  Main loop = the same two-register-set, counted-vmcnt software pipeline as
+// the fp32 kernel (gemm.hip): staged pieces are written to LDS and re-issued in the
 // shadow of the MFMAs.
 #include <type_traits>
 
@@ -26,12 +30,12 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef t2h_f16x8 f16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SP_TILE_B = 192;   // bytes per (row, K tile) in HBM
-constexpr int SP_LDS_ROW = 208;  // bytes per row in LDS
-constexpr int SP_PIECES = 12;    // 16-byte pieces per (row, K tile)
+constexpr int SP_TILE_B = T2H_SPLIT_TILE_B;  // 128 bytes per (row, K tile) in HBM
+constexpr int SP_LDS_ROW = 144;              // bytes per row in LDS
+constexpr int SP_PIECES = 8;                 // 16-byte pieces per (row, K tile)
 
 // Ablation switches for tools/gemm_split_ablate.py (never defined in the product build):
 // T2H_SDBG_NOGLOAD drops the global loads, _NOPUT the LDS stores, _NOFRAG the LDS
@@ -64,13 +68,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
-  // Staging: the (BM + BN) * 12 16-byte pieces of a K tile (A rows first, then B rows)
+  // Staging: the (BM + BN) * 8 16-byte pieces of a K tile (A rows first, then B rows)
   // are dealt round-robin to the NT threads, L per thread.  When NT does not divide the
   // piece count the last round wraps around: those threads re-load a piece another
   // thread also stages and store the identical bytes to the same LDS slot (benign).
   constexpr int PIECES = (BM + BN) * SP_PIECES;
   constexpr int L = (PIECES + NT - 1) / NT;
-  constexpr int NMMA = 2 * 6 * TM * TN;  // MFMAs per wave and K tile
+  constexpr int NMMA = 2 * 3 * TM * TN;  // MFMAs per wave and K tile
   constexpr int BUF_B = (BM + BN) * SP_LDS_ROW;  // bytes per LDS tile buffer: [A rows | B rows]
   constexpr int O_LD = WN + 4;                   // epilogue staging row (floats), odd # of 16-B slots
   constexpr int EPI_B = WM * O_LD * 4 * NWG * KS;
@@ -128,13 +132,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     for (int i = 0; i < L; ++i) gload16_async(rg[S][i], src[i] + k0);
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[2][TM][TN];  // [0] ah*bh, [1] the 2^-11 terms ah*bl + al*bh
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
   using set0 = std::integral_constant<int, 0>;
   using set1 = std::integral_constant<int, 1>;
@@ -149,9 +155,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   issue(set0{}, 2);
   __syncthreads();
 
-  // partial products in increasing magnitude: (a2,b0) (a0,b2) (a1,b1) (a1,b0) (a0,b1) (a0,b0)
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  // partial products (A plane, B plane, accumulator): (l,h) (h,l) -> acc[1], (h,h) -> acc[0]
+  constexpr int PA[3] = {1, 0, 0};
+  constexpr int PB[3] = {0, 1, 0};
+  constexpr int PC[3] = {1, 1, 0};
 
   auto step = [&](int kt, auto setc) {  // register set S holds tile kt+1
     constexpr int S = decltype(setc)::value;
@@ -162,36 +169,36 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     int mma = 0;  // running MFMA count inside the tile (compile-time after unrolling)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {  // two k16 steps per K tile
-      bf16x8 af[TM][3], bfr[TN][3];
+      f16x8 af[TM][2], bfr[TN][2];
 #pragma unroll
       for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < 2; ++pl)
 #ifdef T2H_SDBG_NOFRAG
           asm volatile("" : "=v"(af[ti][pl]) : "v"(Ab));
 #else
-          af[ti][pl] = *reinterpret_cast<const bf16x8*>(Ab + ti * 32 * SP_LDS_ROW + pl * 64 + u * 32);
+          af[ti][pl] = *reinterpret_cast<const f16x8*>(Ab + ti * 32 * SP_LDS_ROW + pl * 64 + u * 32);
 #endif
 #pragma unroll
       for (int tj = 0; tj < TN; ++tj)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < 2; ++pl)
 #ifdef T2H_SDBG_NOFRAG
           asm volatile("" : "=v"(bfr[tj][pl]) : "v"(Bb));
 #else
-          bfr[tj][pl] = *reinterpret_cast<const bf16x8*>(Bb + tj * 32 * SP_LDS_ROW + pl * 64 + u * 32);
+          bfr[tj][pl] = *reinterpret_cast<const f16x8*>(Bb + tj * 32 * SP_LDS_ROW + pl * 64 + u * 32);
 #endif
 #pragma unroll
-      for (int t = 0; t < 6; ++t) {
+      for (int t = 0; t < 3; ++t) {
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
           for (int tj = 0; tj < TN; ++tj) {
 #ifdef T2H_SDBG_NOMMA
-            asm volatile("" : "+v"(acc[ti][tj]) : "v"(af[ti][PA[t]]), "v"(bfr[tj][PB[t]]));
+            asm volatile("" : "+v"(acc[PC[t]][ti][tj]) : "v"(af[ti][PA[t]]), "v"(bfr[tj][PB[t]]));
 #else
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti][PA[t]], bfr[tj][PB[t]],
-                                                                   acc[ti][tj], 0, 0, 0);
+            acc[PC[t]][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ti][PA[t]], bfr[tj][PB[t]],
+                                                                         acc[PC[t]][ti][tj], 0, 0, 0);
 #endif
             ++mma;
             // staged pieces pinned behind the MFMAs of the second half of the tile
@@ -237,11 +244,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = acc[ti][tj][r] + bv;
+        Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] =
+            fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]) + bv;
     }
   __syncthreads();
   if (p.Vt != nullptr && n0 >= p.vt_col0) {
-    // value heads of the q|k|v projection: transposed planes Vt[B][H][3][hd][T].  A chunk is
+    // value heads of the q|k|v projection: transposed planes Vt[B][H][2][hd][T].  A chunk is
     // one output column x 4 consecutive rows (= 4 consecutive keys, which stay adjacent
     // under the key permutation); consecutive lanes take consecutive row groups, so a
     // column's stores are contiguous 8-byte pieces per plane.
@@ -264,15 +272,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       const int cc = col - p.vt_col0, head = cc / p.vt_hd, d = cc - head * p.vt_hd;
       const int w = key & 31;
       const int pos = (key & ~31) + 16 * (w >> 4) + 8 * ((w >> 2) & 1) + 4 * ((w >> 3) & 1);
-      __bf16 sp[3][4];
+      t2h_f16x4 vh, vl;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t2h_split3(v[e], sp[0][e], sp[1][e], sp[2][e]);
-      uint16_t* dstp = p.Vt + ((((int64_t)b * n_vh + head) * 3) * p.vt_hd + d) * p.vt_T + pos;
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        t2h_bf16x4 w4 = {sp[pl][0], sp[pl][1], sp[pl][2], sp[pl][3]};
-        *reinterpret_cast<t2h_bf16x4*>(dstp + (int64_t)pl * p.vt_hd * p.vt_T) = w4;
+      for (int e = 0; e < 4; ++e) {
+        _Float16 x0, x1;
+        t2h_split2(v[e], x0, x1);
+        vh[e] = x0;
+        vl[e] = x1;
       }
+      uint16_t* dstp = p.Vt + ((((int64_t)b * n_vh + head) * 2) * p.vt_hd + d) * p.vt_T + pos;
+      *reinterpret_cast<t2h_f16x4*>(dstp) = vh;
+      *reinterpret_cast<t2h_f16x4*>(dstp + (int64_t)p.vt_hd * p.vt_T) = vl;
     }
     return;
   }
@@ -298,25 +308,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 }
 
 // fp32 [rows, C] (ld) -> split rows; one thread per 4 consecutive columns
-__global__ void split3_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ out, int64_t total,
-                              int C) {
+__global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ out, int64_t total,
+                                  int C) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over rows * C/4
   if (i >= total) return;
   const int q = C >> 2;
   const int64_t row = i / q;
   const int c0 = (int)(i - row * q) * 4;
-  const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c0);
-  __bf16 s[3][4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) t2h_split3(v[e], s[0][e], s[1][e], s[2][e]);
-  char* d = reinterpret_cast<char*>(out) + row * (int64_t)(C / 32) * SP_TILE_B + (c0 >> 5) * SP_TILE_B +
-            (c0 & 31) * 2;
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    bf16x4 w = {s[pl][0], s[pl][1], s[pl][2], s[pl][3]};
-    *reinterpret_cast<bf16x4*>(d + pl * 64) = w;
-  }
+  t2h_store_split4(out, row, C, c0, *reinterpret_cast<const f32x4*>(x + row * ldx + c0));
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1>
@@ -370,18 +369,17 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64
     case 2: return launch_split<64, 64, 2, 2>(a, s);    // 4 waves, wave tile 32x32
     case 3: return launch_split<128, 64, 4, 2>(a, s);   // 8 waves, wave tile 32x32
-    case 4: return launch_split<128, 192, 4, 2>(a, s);  // 8 waves, wave tile 32x96
     case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
     case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
     default: return launch_split<128, 64, 2, 2>(a, s);  // 4 waves, wave tile 64x32
   }
 }
 
-extern "C" int t2h_split3_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream) {
-  T2H_REQUIRE(x && out && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0, "t2h_split3_f32: bad arguments");
+extern "C" int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream) {
+  T2H_REQUIRE(x && out && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0, "t2h_split_rows_f32: bad arguments");
   const int64_t total = rows * (C / 4);
-  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ldx, out, total, C);
-  T2H_CHECK_LAUNCH("t2h_split3_f32");
+  T2H_CHECK_LAUNCH("t2h_split_rows_f32");
   return T2H_OK;
 }

@@ -5,7 +5,7 @@ namespace {
 
 // One wave per row; each lane keeps its C/64 values in registers, two passes
 // (mean, then centred variance) like torch's rowwise moments.
-// SPLIT: the result is written as split rows (three bf16 planes) for the
+// SPLIT: the result is written as split rows (two fp16 planes) for the
 // split-precision GEMM instead of fp32.
 template <int VPL, bool SPLIT = false>  // float4 vectors per lane: C = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,

@@ -129,10 +129,15 @@ class SamplerNet:
     tail kernel.  24 x [LN, QKV GEMM, flash MHA, proj GEMM(+res), LN, fc1
     GEMM(+GELU), fc2 GEMM(+res)]."""
 
-    def __init__(self, P, desc, n_head, name='tf', fuse_ln=False, split=False, split_mha=True):
+    def __init__(self, P, desc, n_head, name='tf', fuse_ln=False, split=False, split_mha=True, n_streams=1):
         self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
         self.split = split
-        # split_mha (with split): attention on the bf16 matrix cores too -- the q|k|v
+        # n_streams > 1 (split path): the batch is cut into that many independent slices
+        # whose 24-layer kernel chains run on separate HIP streams, so one slice's launch
+        # latency / first-tile fill / epilogue tail overlaps the other's main loops
+        self.n_streams = n_streams
+        self._streams = None
+        # split_mha (with split): attention on the fp16 matrix cores too -- the q|k|v
         # projection writes q, k as split rows and v as transposed planes, no fp32 qkv
         self.split_mha = split_mha
         # fuse_ln: LayerNorm folded into the GEMM operand staging + statistics from
@@ -164,8 +169,8 @@ class SamplerNet:
         ops.embed_sum4(idx, segm_tok, tex_tok, P[f'{nm}.tok_emb'], P[f'{nm}.pos_emb'],
                        P[f'{nm}.segm_emb'], P[f'{nm}.tex_emb'], out=x)
         if self.split:
-            # Split-precision path: the four Linears run on the bf16 matrix cores with
-            # 3 x bf16 planes per operand (fp32-class accuracy, gemm_split.hip).  The
+            # Split-precision path: the four Linears run on the fp16 matrix cores with
+            # 2 x fp16 planes per operand (fp32-class accuracy, gemm_split.hip).  The
             # producers write split rows directly: LayerNorm -> h, attention -> y,
             # fc1's GELU epilogue -> u; the residual stream x and q|k|v stay fp32.
             M = B * T
@@ -173,22 +178,48 @@ class SamplerNet:
             vt = buf['vt']
             if self.split_mha and tuple(vt.shape) != (B, self.n_head, 3, C // self.n_head, T):
                 vt = buf['vt'] = ops.vt_empty(B, self.n_head, T, idx.device, C // self.n_head)
-            for i in range(self.desc['n_layers']):
+            qks = buf['qk_split']
+            ns = self.n_streams if (self.split_mha and B % max(self.n_streams, 1) == 0) else 1
+            # batch slices: (rows lo:hi, batch size); all buffers are row-major over B*T rows
+            Bs = B // ns
+            sl = [(j * Bs * T, (j + 1) * Bs * T, j * Bs, (j + 1) * Bs) for j in range(ns)]
+
+            def layer(i, lo, hi, b0, b1):
                 p = f'{nm}.{i}'
-                ops.layernorm_split(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs)
+                m, xs = hi - lo, x[lo:hi]
+                ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])
                 if self.split_mha:
-                    ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out_split=buf['qk_split'],
-                                   bias=P[f'{p}.qkv.b'], vt=vt, vt_col0=2 * C, vt_T=T, vt_hd=C // self.n_head)
-                    ops.mha_split(buf['qk_split'], 3 * C, vt, B, T, self.n_head, out_split=ys)
+                    ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out_split=qks[lo:hi],
+                                   bias=P[f'{p}.qkv.b'], vt=vt[b0:b1], vt_col0=2 * C, vt_T=T,
+                                   vt_hd=C // self.n_head)
+                    ops.mha_split(qks[lo:hi], 3 * C, vt[b0:b1], b1 - b0, T, self.n_head, out_split=ys[lo:hi])
                 else:
-                    ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out=qkv, bias=P[f'{p}.qkv.b'])
-                    ops.mha_noncausal_split(qkv, B, T, self.n_head, ys)
-                ops.gemm_split(ys, P[f'{p}.proj.w_split'], M, C, C, out=x, bias=P[f'{p}.proj.b'], residual=x)
-                ops.layernorm_split(x, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs)
-                ops.gemm_split(hs, P[f'{p}.fc1.w_split'], M, 4 * C, C, out_split=us, bias=P[f'{p}.fc1.b'],
-                               act=ACT_GELU)
-                ops.gemm_split(us, P[f'{p}.fc2.w_split'], M, C, 4 * C, out=x, bias=P[f'{p}.fc2.b'],
-                               residual=x)
+                    ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out=qkv[lo:hi],
+                                   bias=P[f'{p}.qkv.b'])
+                    ops.mha_noncausal_split(qkv[lo:hi], b1 - b0, T, self.n_head, ys[lo:hi])
+                ops.gemm_split(ys[lo:hi], P[f'{p}.proj.w_split'], m, C, C, out=xs, bias=P[f'{p}.proj.b'],
+                               residual=xs)
+                ops.layernorm_split(xs, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs[lo:hi])
+                ops.gemm_split(hs[lo:hi], P[f'{p}.fc1.w_split'], m, 4 * C, C, out_split=us[lo:hi],
+                               bias=P[f'{p}.fc1.b'], act=ACT_GELU)
+                ops.gemm_split(us[lo:hi], P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xs, bias=P[f'{p}.fc2.b'],
+                               residual=xs)
+
+            if ns == 1:
+                for i in range(self.desc['n_layers']):
+                    layer(i, *sl[0])
+                return x
+            if self._streams is None or len(self._streams) != ns:
+                self._streams = [torch.cuda.Stream(device=idx.device) for _ in range(ns)]
+            main = torch.cuda.current_stream()
+            for st in self._streams:
+                st.wait_stream(main)
+            for i in range(self.desc['n_layers']):
+                for j, st in enumerate(self._streams):
+                    with torch.cuda.stream(st):
+                        layer(i, *sl[j])
+            for st in self._streams:
+                main.wait_stream(st)
             return x
         if self.fuse_ln:
             # LayerNorm never materialises: the residual GEMMs (proj, fc2) emit the

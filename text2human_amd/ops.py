@@ -204,35 +204,49 @@ def layernorm(x, gamma, beta, out=None, eps=1e-5):
 
 
 def split_rows_empty(rows, C, device):
-    """Uninitialised split-row buffer [rows][C/32][3][32] bf16 (as int16)."""
-    return torch.empty((rows, C // 32, 3, 32), device=device, dtype=torch.int16)
+    """Uninitialised split-row buffer [rows][C/32][2][32] fp16 (as int16)."""
+    return torch.empty((rows, C // 32, 2, 32), device=device, dtype=torch.int16)
 
 
-def split3(x, out=None):
-    """fp32 x [rows, C] (unit inner stride) -> split rows (x = x0 + x1 + x2, bf16 planes)."""
+SPLIT_LO_SCALE = 2048.0
+
+
+def split_planes_host(x):
+    """(hi, lo) fp16 planes of an fp32 tensor: x = hi + lo / 2048 (round-to-nearest-even,
+    bit-identical to the device split)."""
+    x = x.float()
+    hi = x.half()
+    lo = ((x - hi.float()) * SPLIT_LO_SCALE).half()
+    return hi, lo
+
+
+def unsplit_rows_host(s, rows, C):
+    """split rows (int16 view, any device) -> fp32 [rows, C] on the CPU"""
+    pl = s.cpu().view(torch.float16).view(rows, C // 32, 2, 32).float()
+    return (pl[:, :, 0] + pl[:, :, 1] / SPLIT_LO_SCALE).reshape(rows, C)
+
+
+def split_rows(x, out=None):
+    """fp32 x [rows, C] (unit inner stride) -> split rows (x = hi + lo / 2048, fp16 planes)."""
     _chk_f32(x)
     rows, C = x.shape
     if out is None:
         out = split_rows_empty(rows, C, x.device)
-    check(_lib.load().t2h_split3_f32(_p(x), _rows(x), _p(out), rows, C, _stream()), 't2h_split3_f32')
+    check(_lib.load().t2h_split_rows_f32(_p(x), _rows(x), _p(out), rows, C, _stream()), 't2h_split_rows_f32')
     return out
 
 
 def pack_split_rows_host(w):
     """Host-side (torch CPU) repack of an fp32 matrix [N, K] into split rows."""
-    w = w.float()
-    p0 = w.bfloat16()
-    r1 = w - p0.float()
-    p1 = r1.bfloat16()
-    p2 = (r1 - p1.float()).bfloat16()
+    hi, lo = split_planes_host(w)
     n, k = w.shape
-    planes = torch.stack([p0, p1, p2], 0).view(3, n, k // 32, 32).permute(1, 2, 0, 3).contiguous()
+    planes = torch.stack([hi, lo], 0).view(2, n, k // 32, 32).permute(1, 2, 0, 3).contiguous()
     return planes.view(torch.int16)
 
 
 def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE,
                vt=None, vt_col0=0, vt_T=0, vt_hd=64):
-    """C = act(A @ W^T + bias) + residual on the bf16 matrix cores at fp32-class
+    """C = act(A @ W^T + bias) + residual on the fp16 matrix cores at fp32-class
     accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
     split-row form `out_split` of the result.  With `vt` the output columns from
     `vt_col0` on go to the transposed value planes of mha_split instead
@@ -254,20 +268,20 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     if _prof is not None:
         _prof['count'] += 1
         if _prof['count'] % _prof['every'] == 0:
-            # algorithmic (fp32-equivalent) FLOPs; the kernel issues 6 bf16 products per multiply
+            # algorithmic (fp32-equivalent) FLOPs; the kernel issues 3 fp16 products per multiply
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
             e1.record()
-            _prof['recs'].append(('gemm_split_kernel<3xbf16>', 2.0 * M * N * K, e0, e1))
+            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, e0, e1))
             return out if out is not None else out_split
     check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
     return out if out is not None else out_split
 
 
 def vt_empty(B, n_head, T, device, hd=64):
-    """Transposed value planes [B][H][3][hd][T] bf16 (as int16) for mha_split."""
-    return torch.empty(B, n_head, 3, hd, T, dtype=torch.int16, device=device)
+    """Transposed value planes [B][H][2][hd][T] fp16 (as int16) for mha_split."""
+    return torch.empty(B, n_head, 2, hd, T, dtype=torch.int16, device=device)
 
 
 def vt_key_positions(T):
@@ -279,7 +293,7 @@ def vt_key_positions(T):
 
 def mha_split(qk_split, ld_cols, vt, B, T, n_head, out=None, out_split=None):
     """Attention with q, k read as split rows and v as transposed planes; both
-    products as six bf16 partial products (fp32-class accuracy)."""
+    products as three fp16 partial products (fp32-class accuracy)."""
     _chk_f32(out)
     check(_lib.load().t2h_mha_split_f32(_p(qk_split), ld_cols, _p(vt), _p(out) if out is not None else None,
                                         _p(out_split) if out_split is not None else None, B, T, n_head,

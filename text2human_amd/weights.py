@@ -163,7 +163,7 @@ def pack_transformer(P, sd, dst='tf'):
             P.put(f'{d}.{ln}.b', sd[f'{s}.{ln}.bias'])
         P.put(f'{d}.qkv.w', torch.cat([sd[f'{s}.attn.{n}.weight'] for n in ('query', 'key', 'value')], 0))
         P.put(f'{d}.qkv.b', torch.cat([sd[f'{s}.attn.{n}.bias'] for n in ('query', 'key', 'value')], 0))
-        # split rows (3 x bf16 planes) of the four Linears for the split-precision GEMM
+        # split rows (2 x fp16 planes) of the four Linears for the split-precision GEMM
         from . import ops as _ops
         for lin, key in (('qkv', None), ('proj', f'{s}.attn.proj.weight'), ('fc1', f'{s}.mlp.0.weight'),
                          ('fc2', f'{s}.mlp.2.weight')):

@@ -28,8 +28,8 @@ for tag, extra in VARIANTS:
     lib = ctypes.CDLL(so)
     line = f'{tag:14s}'
     for (n, k) in ((1536, 512), (512, 512), (2048, 512), (512, 2048)):
-        a = torch.zeros(M * k * 3, dtype=torch.int16, device='cuda')
-        w = torch.zeros(n * k * 3, dtype=torch.int16, device='cuda')
+        a = torch.zeros(M * k * 2, dtype=torch.int16, device='cuda')
+        w = torch.zeros(n * k * 2, dtype=torch.int16, device='cuda')
         out = torch.empty(M, n, device='cuda')
         g = GemmSplitArgs()
         g.A, g.B, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()

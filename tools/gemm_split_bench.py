@@ -1,4 +1,4 @@
-"""A/B of the split-precision (3xbf16, 6 products) GEMM against the exact-fp32
+"""A/B of the split-precision (2xfp16, 3 products) GEMM against the exact-fp32
 MFMA GEMM on the sampler shapes: accuracy vs an fp64 reference and time.  GPU only."""
 import os
 import sys
@@ -26,7 +26,7 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    CFGS = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else list(range(7))
+    CFGS = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 1, 2, 3, 5, 6]
     M = B * 512
     g = torch.Generator().manual_seed(0)
     shapes = {'qkv': (M, 1536, 512), 'proj': (M, 512, 512), 'fc1': (M, 2048, 512), 'fc2': (M, 512, 2048)}
@@ -41,12 +41,12 @@ def main():
         ops.gemm(a, w, out=out, bias=bias)
         e32 = (out.double() - ref).abs().max().item()
         t32 = timeit(lambda: ops.gemm(a, w, out=out, bias=bias))
-        a_s = ops.split3(a)
+        a_s = ops.split_rows(a)
         w_s = ops.pack_split_rows_host(w.cpu()).to(DEV)
-        w_s2 = ops.split3(w)
+        w_s2 = ops.split_rows(w)
         assert torch.equal(w_s, w_s2.view_as(w_s)), 'device split != host split'
-        t_split3 = timeit(lambda: ops.split3(a, out=a_s))
-        line = f'{name:5s} M{m} N{n} K{k} | fp32: {t32:6.1f} us err {e32:.2e} | split3(A) {t_split3:5.1f} us |'
+        t_split3 = timeit(lambda: ops.split_rows(a, out=a_s))
+        line = f'{name:5s} M{m} N{n} K{k} | fp32: {t32:6.1f} us err {e32:.2e} | split(A) {t_split3:5.1f} us |'
         for cfg in CFGS:
             lib.t2h_gemm_split_force_config(cfg)
             ops.gemm_split(a_s, w_s, m, n, k, out=out, bias=bias)
@@ -57,8 +57,8 @@ def main():
         # split-row output round trip
         o_s = ops.split_rows_empty(m, n, DEV)
         ops.gemm_split(a_s, w_s, m, n, k, out_split=o_s, bias=bias, act=ops.ACT_GELU)
-        planes = o_s.view(torch.bfloat16).float().sum(2).reshape(m, n)
-        eg = (planes.double() - torch.nn.functional.gelu(ref)).abs().max().item()
+        planes = ops.unsplit_rows_host(o_s, m, n)
+        eg = (planes.double() - torch.nn.functional.gelu(ref.cpu())).abs().max().item()
         print(line + f' gelu+split-out err {eg:.2e} | ref scale {scale:.2f}')
 
 

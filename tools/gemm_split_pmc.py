@@ -19,8 +19,8 @@ def main():
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
     for n, k in ((1536, 512), (512, 512), (2048, 512), (512, 2048)):
-        a_s = ops.split3(torch.randn(M, k, generator=g).cuda())
-        w_s = ops.split3((torch.randn(n, k, generator=g) * 0.05).cuda())
+        a_s = ops.split_rows(torch.randn(M, k, generator=g).cuda())
+        w_s = ops.split_rows((torch.randn(n, k, generator=g) * 0.05).cuda())
         out = torch.empty(M, n, device='cuda')
         lib.t2h_gemm_split_force_config(cfg)
         for _ in range(iters):
