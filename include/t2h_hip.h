@@ -182,9 +182,12 @@ int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int32_t T,
 
 /* one step of the absorbing-diffusion unmasking schedule
  * (models/sample_model.py:286-292,301-302): changes = rand < 1/t & ~unmasked;
- * unmasked |= changes; head_count[h] += #changed tokens of texture h. */
+ * unmasked |= changes; head_count[h] += #changed tokens of texture h.  With
+ * changed_rows (or NULL): the changed token rows are also appended to that list (any
+ * order) and counted in head_count[n_heads]. */
 int t2h_unmask_step(const float* rand, int32_t t, uint8_t* unmasked, uint8_t* changes,
-                    const int64_t* tex, int32_t* head_count, int32_t n, void* stream);
+                    const int64_t* tex, int32_t* head_count, int32_t n, int32_t* changed_rows,
+                    int32_t n_heads, void* stream);
 
 /* texture-routed categorical sampling of the changed tokens of ONE head
  * (models/sample_model.py:304-317 + ln_f and head_list[h] of
@@ -197,6 +200,25 @@ int t2h_sample_head(const float* hidden, const float* lnf_gamma, const float* ln
                     const int64_t* tex, int32_t head, float temp, int64_t* x_t,
                     int64_t* out_idx, int32_t n, int32_t C, int32_t n_class,
                     void* stream);
+
+/* the same for ALL heads in one launch over the compact list of changed rows: row r is
+ * sampled with head h = tex[r], weights w_heads[h], noise expo[h] (the reference's per
+ * ACTIVE head draw, in head order; NULL for heads that drew none), out_idx[h][r]. */
+#define T2H_MAX_HEADS 32
+typedef struct t2h_sample_heads_args {
+  const float* hidden;      /* [n, C] transformer output before ln_f */
+  const float* lnf_gamma;
+  const float* lnf_beta;
+  const float* w_heads;     /* [n_heads][n_class][C] */
+  const float* expo[T2H_MAX_HEADS];
+  const int32_t* rows;      /* changed rows (t2h_unmask_step) */
+  const int64_t* tex;
+  int64_t* x_t;
+  int64_t* out_idx;         /* [n_heads][n] */
+  float temp;
+  int32_t n_rows, n, C, n_class, n_heads;
+} t2h_sample_heads_args;
+int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream);
 
 /* ------------------------------------------------------ quantizers ---------
  * VectorQuantizer.forward distance+argmin, vqgan_arch.py:88-92 (first min wins) */

@@ -213,6 +213,14 @@ def test_unmask_step():
         assert torch.equal(ch.cpu().bool(), changes)
         assert torch.equal(unm.cpu().bool(), um | changes)
         assert torch.equal(cnt.cpu().long(), torch.bincount(tex[changes], minlength=18))
+        # compact list of the changed rows (any order) + their total in cnt[18]
+        unm2 = um.to(torch.uint8).to(DEV)
+        cnt2 = torch.zeros(19, dtype=torch.int32, device=DEV)
+        rows = torch.full((n, ), -1, dtype=torch.int32, device=DEV)
+        ops.unmask_step(r.to(DEV), t, unm2, ch, tex.to(DEV), cnt2, rows, 18)
+        k = int(cnt2[18])
+        assert k == int(changes.sum()) and torch.equal(cnt2[:18].cpu(), cnt.cpu())
+        assert torch.equal(rows[:k].cpu().long().sort().values, torch.nonzero(changes).flatten())
 
 
 def test_sample_head_matches_categorical_race():
@@ -242,6 +250,29 @@ def test_sample_head_matches_categorical_race():
     mism = sel & (got != ref)
     assert (margin[mism] < 1e-5).all(), f'{int(mism.sum())} mismatches beyond near-tie margin'
     assert torch.equal(xt[sel & ~mism], ref[sel & ~mism] + 1024 * head)
+
+
+def test_sample_heads_one_launch_equals_per_head_launches():
+    n, C, K, H = 512, 512, 1024, 18
+    hidden, g, b = rnd(n, C, seed=45) * 2, rnd(C, seed=46) * 0.1 + 1, rnd(C, seed=47) * 0.1
+    w = rnd(H, K, C, seed=48, scale=0.15)
+    gen = torch.Generator().manual_seed(49)
+    tex = torch.randint(0, H, (n, ), generator=gen)
+    tex[tex == 11] = 3                                   # head 11 inactive
+    changes = (torch.rand(n, generator=gen) < 0.2)
+    active = sorted(set(tex[changes].tolist()))
+    expo = {h: torch.empty(n, K).exponential_(1.0, generator=gen).to(DEV) for h in active}
+    dv = lambda t: t.to(DEV)
+    hidden, g, b, w, texd, chd = dv(hidden), dv(g), dv(b), dv(w), dv(tex), dv(changes.to(torch.uint8))
+    x_a = torch.full((n, ), 18432, dtype=torch.int64, device=DEV)
+    out_a = torch.full((H, n), -1, dtype=torch.int64, device=DEV)
+    for h in active:
+        ops.sample_head(hidden, g, b, w[h], expo[h], chd, texd, h, 1.0, x_a, out_a[h])
+    x_b, out_b = torch.full_like(x_a, 18432), torch.full_like(out_a, -1)
+    rows = torch.nonzero(changes).flatten().flip(0).to(torch.int32).to(DEV)   # any order
+    ops.sample_heads(hidden, g, b, w, expo, rows, rows.numel(), texd, 1.0, x_b, out_b)
+    assert (out_a >= 0).sum() == int(changes.sum())
+    assert torch.equal(x_a, x_b) and torch.equal(out_a, out_b)
 
 
 # ------------------------------------------------------------------ quantizer pieces

@@ -151,9 +151,10 @@ def test_sampler_net_split_mha_on_and_off_agree_with_oracle():
     args = (idx.to(DEV), seg.to(DEV), tex.to(DEV))
     a = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=False).hidden(*args).clone().cpu()
     b = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=True).hidden(*args).clone().cpu()
-    # batch slices on separate streams run the same kernels on the same rows
+    # batch slices on separate streams: same rows, same math (the GEMM tile config, hence
+    # the summation order, may differ with the slice's row count)
     c = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=True, n_streams=3).hidden(*args).clone().cpu()
-    assert torch.equal(b, c)
+    assert (b - c).abs().max().item() < 2e-4 * b.abs().max().item()
     with torch.no_grad():
         ref = R.transformer_hidden(idx, seg, tex, sd)
     ln = lambda t: F.layer_norm(t.view(3, 512, 512), (512, ), sd['ln_f.weight'], sd['ln_f.bias'], 1e-5)

@@ -45,6 +45,18 @@ class GemmSplitArgs(ctypes.Structure):
     ]
 
 
+MAX_HEADS = 32
+
+
+class SampleHeadsArgs(ctypes.Structure):
+    """struct t2h_sample_heads_args (include/t2h_hip.h)."""
+    _fields_ = [
+        ('hidden', c_vp), ('lnf_gamma', c_vp), ('lnf_beta', c_vp), ('w_heads', c_vp),
+        ('expo', c_vp * MAX_HEADS), ('rows', c_vp), ('tex', c_vp), ('x_t', c_vp), ('out_idx', c_vp),
+        ('temp', c_f32), ('n_rows', c_i32), ('n', c_i32), ('C', c_i32), ('n_class', c_i32), ('n_heads', c_i32),
+    ]
+
+
 # name -> (restype, argtypes); must list EVERY symbol declared in include/t2h_hip.h
 SIGNATURES = {
     't2h_gemm_split_f32': (ctypes.c_int, [ctypes.POINTER(GemmSplitArgs), c_vp]),
@@ -66,7 +78,8 @@ SIGNATURES = {
     't2h_softmax_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_embed_sum4_f32': (ctypes.c_int, [c_vp] * 8 + [c_i32, c_i32, c_i32, c_vp]),
     't2h_mha_noncausal_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    't2h_unmask_step': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    't2h_unmask_step': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    't2h_sample_heads': (ctypes.c_int, [ctypes.POINTER(SampleHeadsArgs), c_vp]),
     't2h_sample_head': (ctypes.c_int, [c_vp] * 7 + [c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_vq_l2_argmin_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_codebook_gather_tex_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),

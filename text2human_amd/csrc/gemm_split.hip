@@ -360,10 +360,13 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
   hipStream_t s = static_cast<hipStream_t>(stream);
   int cfg = g_force_split_cfg;
   if (cfg < 0) {
-    // measured on MI355X at M = 4096 (tools/gemm_split_bench.py): the 4-wave 128x64
-    // tile wins on every sampler shape; 128x128 only pays once it still fills 2x256 CUs
+    // measured on MI355X at M = 4096 (tools/gemm_split_bench.py, profiles/): the 4-wave
+    // 128x64 tile wins wherever it gives every CU at least two tiles; when it gives at
+    // most one (N = 512) the same tile with the in-block K split (two waves per SIMD)
+    // is 5-8 % faster; 128x128 only pays once it still fills 2 x 256 CUs
+    const int64_t tiles64 = (int64_t)((a.M + 127) / 128) * ((a.N + 63) / 64);
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    cfg = a.M <= 64 ? 2 : (tiles128 >= 1024 ? 1 : 0);
+    cfg = a.M <= 64 ? 2 : (tiles128 >= 1024 ? 1 : ((tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) ? 6 : 0));
   }
   switch (cfg) {
     case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64

@@ -59,10 +59,12 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
 
 // changes = rand < 1/t ; changes &= ~unmasked ; unmasked |= changes
 // (models/sample_model.py:286-292).  `1 / t.float()` is an fp32 reciprocal.
+// With changed_rows: the changed tokens are also appended to that list (in no particular
+// order -- every row is sampled independently) and counted in head_count[n_heads].
 __global__ void unmask_step_kernel(const float* __restrict__ rnd, float thresh,
                                    uint8_t* __restrict__ unmasked, uint8_t* __restrict__ changes,
                                    const int64_t* __restrict__ tex, int* __restrict__ head_count,
-                                   int n) {
+                                   int n, int* __restrict__ changed_rows, int n_heads) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const bool um = unmasked[i] != 0;
@@ -71,6 +73,7 @@ __global__ void unmask_step_kernel(const float* __restrict__ rnd, float thresh,
   if (ch) {
     unmasked[i] = 1;
     atomicAdd(head_count + (int)tex[i], 1);
+    if (changed_rows) changed_rows[atomicAdd(head_count + n_heads, 1)] = i;
   }
 }
 
@@ -80,14 +83,11 @@ __global__ void unmask_step_kernel(const float* __restrict__ rnd, float thresh,
 constexpr int SH_THREADS = 1024;
 
 template <int C>
-__global__ __launch_bounds__(SH_THREADS) void sample_head_kernel(
-    const float* __restrict__ hidden, const float* __restrict__ g, const float* __restrict__ bta,
-    const float* __restrict__ w, const float* __restrict__ expo, const uint8_t* __restrict__ changes,
-    const int64_t* __restrict__ tex, int head, float inv_temp, int64_t* __restrict__ x_t,
-    int64_t* __restrict__ out_idx, int n_class) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // n_class logits + 2*NW reduce slots
-  const int row = blockIdx.x;
-  if (!changes[row] || (int)tex[row] != head) return;
+__device__ __forceinline__ void sample_row(float* lds, int row, const float* __restrict__ hidden,
+                                           const float* __restrict__ g, const float* __restrict__ bta,
+                                           const float* __restrict__ w, const float* __restrict__ expo, int head,
+                                           float inv_temp, int64_t* __restrict__ x_t,
+                                           int64_t* __restrict__ out_idx, int n_class) {
   constexpr int VPL = C / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xr = hidden + (int64_t)row * C;
@@ -187,6 +187,31 @@ __global__ __launch_bounds__(SH_THREADS) void sample_head_kernel(
   }
 }
 
+template <int C>
+__global__ __launch_bounds__(SH_THREADS) void sample_head_kernel(
+    const float* __restrict__ hidden, const float* __restrict__ g, const float* __restrict__ bta,
+    const float* __restrict__ w, const float* __restrict__ expo, const uint8_t* __restrict__ changes,
+    const int64_t* __restrict__ tex, int head, float inv_temp, int64_t* __restrict__ x_t,
+    int64_t* __restrict__ out_idx, int n_class) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // n_class logits + 2*NW reduce slots
+  const int row = blockIdx.x;
+  if (!changes[row] || (int)tex[row] != head) return;
+  sample_row<C>(lds, row, hidden, g, bta, w, expo, head, inv_temp, x_t, out_idx, n_class);
+}
+
+// All heads in one launch: one workgroup per CHANGED token (compact list from
+// unmask_step), which picks the head / noise tensor of its own texture.
+template <int C>
+__global__ __launch_bounds__(SH_THREADS) void sample_heads_kernel(const t2h_sample_heads_args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int row = a.rows[blockIdx.x];
+  const int head = (int)a.tex[row];
+  const float* expo = a.expo[head];
+  if (expo == nullptr) return;  // cannot happen: a head with changed tokens always drew its noise
+  sample_row<C>(lds, row, a.hidden, a.lnf_gamma, a.lnf_beta, a.w_heads + (int64_t)head * a.n_class * C, expo, head,
+                1.0f / a.temp, a.x_t, a.out_idx + (int64_t)head * a.n, a.n_class);
+}
+
 }  // namespace
 
 extern "C" int t2h_embed_sum4_f32(const int64_t* idx, const int64_t* segm, const int64_t* tex,
@@ -219,13 +244,14 @@ extern "C" int t2h_row_stats_f32(const float* x, float* stats, int32_t rows, int
 }
 
 extern "C" int t2h_unmask_step(const float* rnd, int32_t t, uint8_t* unmasked, uint8_t* changes,
-                               const int64_t* tex, int32_t* head_count, int32_t n, void* stream) {
+                               const int64_t* tex, int32_t* head_count, int32_t n, int32_t* changed_rows,
+                               int32_t n_heads, void* stream) {
   T2H_REQUIRE(rnd && unmasked && changes && tex && head_count, "t2h_unmask_step: NULL pointer");
-  T2H_REQUIRE(t >= 1 && n > 0, "t2h_unmask_step: t=%d n=%d", t, n);
+  T2H_REQUIRE(t >= 1 && n > 0 && n_heads >= 0, "t2h_unmask_step: t=%d n=%d", t, n);
   const float thresh = 1.0f / (float)t;
   hipLaunchKernelGGL(unmask_step_kernel, dim3((n + 255) / 256), dim3(256), 0,
                      static_cast<hipStream_t>(stream), rnd, thresh, unmasked, changes, tex,
-                     head_count, n);
+                     head_count, n, changed_rows, n_heads);
   T2H_CHECK_LAUNCH("t2h_unmask_step");
   return T2H_OK;
 }
@@ -244,5 +270,22 @@ extern "C" int t2h_sample_head(const float* hidden, const float* lnf_gamma, cons
                      static_cast<hipStream_t>(stream), hidden, lnf_gamma, lnf_beta, w_head, expo,
                      changes, tex, head, 1.0f / temp, x_t, out_idx, n_class);
   T2H_CHECK_LAUNCH("t2h_sample_head");
+  return T2H_OK;
+}
+
+extern "C" int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream) {
+  T2H_REQUIRE(args != nullptr, "t2h_sample_heads: args is NULL");
+  const t2h_sample_heads_args a = *args;
+  T2H_REQUIRE(a.hidden && a.lnf_gamma && a.lnf_beta && a.w_heads && a.rows && a.tex && a.x_t && a.out_idx,
+              "t2h_sample_heads: NULL pointer");
+  T2H_REQUIRE(a.n > 0 && a.n_class > 0 && a.temp > 0.f && a.n_rows >= 0 && a.n_heads > 0 &&
+                  a.n_heads <= T2H_MAX_HEADS,
+              "t2h_sample_heads: bad arguments");
+  T2H_REQUIRE(a.C == 512, "t2h_sample_heads: C=%d unsupported (512)", a.C);
+  if (a.n_rows == 0) return T2H_OK;
+  const size_t lds = (size_t)(a.n_class + 2 * (SH_THREADS / 64)) * sizeof(float);
+  hipLaunchKernelGGL(sample_heads_kernel<512>, dim3(a.n_rows), dim3(SH_THREADS), lds,
+                     static_cast<hipStream_t>(stream), a);
+  T2H_CHECK_LAUNCH("t2h_sample_heads");
   return T2H_OK;
 }

@@ -298,24 +298,28 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     unmasked = torch.zeros(n, dtype=torch.uint8, device=dev)
     changes = torch.zeros(n, dtype=torch.uint8, device=dev)
     out = torch.full((n_books, n), -1, dtype=torch.int64, device=dev)
-    counts = torch.zeros(n_books, dtype=torch.int32, device=dev)
-    counts_host = torch.zeros(n_books, dtype=torch.int32).pin_memory()
+    counts = torch.zeros(n_books + 1, dtype=torch.int32, device=dev)  # per head + total
+    counts_host = torch.zeros(n_books + 1, dtype=torch.int32).pin_memory()
+    rows = torch.empty(n, dtype=torch.int32, device=dev)               # compact list of changed rows
     tex_flat = tex_tok.reshape(-1).contiguous()
     n_class = P[f'{nm}.heads'].shape[1]
     ev = torch.cuda.Event()
     for t in range(sample_steps, 0, -1):
         rnd = noise.uniform(t, (B, T)).to(dev, torch.float32).contiguous()
         counts.zero_()
-        ops.unmask_step(rnd, t, unmasked, changes, tex_flat, counts)
+        ops.unmask_step(rnd, t, unmasked, changes, tex_flat, counts, rows, n_books)
         counts_host.copy_(counts, non_blocking=True)
         ev.record()
         hidden = net.hidden(x_t, segm_tok, tex_tok)
         ev.synchronize()
-        active = torch.nonzero(counts_host).flatten().tolist()
-        for cb in active:
-            expo = noise.exponential(t, cb, (n, n_class)).to(dev, torch.float32).contiguous()
-            ops.sample_head(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'][cb], expo,
-                            changes, tex_flat, cb, temp, x_t, out[cb])
+        active = torch.nonzero(counts_host[:n_books]).flatten().tolist()
+        if not active:
+            continue
+        # the reference's draws, one full tensor per active head in ascending head order;
+        # then ONE launch samples every changed token with the head of its texture
+        expo = {cb: noise.exponential(t, cb, (n, n_class)).to(dev, torch.float32).contiguous() for cb in active}
+        ops.sample_heads(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'], expo, rows,
+                         int(counts_host[n_books]), tex_flat, temp, x_t, out)
     return out
 
 

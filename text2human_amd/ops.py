@@ -377,11 +377,36 @@ def mha_noncausal(qkv, B, T, n_head, out=None):
     return out
 
 
-def unmask_step(rand, t, unmasked, changes, tex, head_count):
+def unmask_step(rand, t, unmasked, changes, tex, head_count, changed_rows=None, n_heads=0):
+    """head_count: int32 [n_heads (+1)]; with changed_rows (int32 [n]) the changed rows are
+    appended to it and counted in head_count[n_heads]."""
     _chk_f32(rand)
     n = rand.numel()
+    if changed_rows is not None:
+        assert changed_rows.dtype == torch.int32 and changed_rows.numel() >= n
+        assert head_count.numel() > n_heads
     check(_lib.load().t2h_unmask_step(_p(rand), int(t), _p(unmasked), _p(changes), _p(tex),
-                                      _p(head_count), n, _stream()), 't2h_unmask_step')
+                                      _p(head_count), n, _p(changed_rows), int(n_heads), _stream()),
+          't2h_unmask_step')
+
+
+def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex, temp, x_t, out_idx):
+    """All heads in one launch: `rows` (int32, first n_rows valid) are the changed token
+    rows, expo_by_head {head: [n, n_class] Exp(1) draw}, w_heads [n_heads, n_class, C],
+    out_idx [n_heads, n]."""
+    _chk_f32(hidden, lnf_g, lnf_b, w_heads, *expo_by_head.values())
+    n, C = hidden.shape
+    n_heads, n_class = w_heads.shape[0], w_heads.shape[1]
+    assert w_heads.is_contiguous() and out_idx.is_contiguous() and out_idx.shape == (n_heads, n)
+    a = _lib.SampleHeadsArgs()
+    a.hidden, a.lnf_gamma, a.lnf_beta, a.w_heads = (hidden.data_ptr(), lnf_g.data_ptr(), lnf_b.data_ptr(),
+                                                    w_heads.data_ptr())
+    for h, e in expo_by_head.items():
+        assert e.shape == (n, n_class) and e.is_contiguous()
+        a.expo[h] = e.data_ptr()
+    a.rows, a.tex, a.x_t, a.out_idx = rows.data_ptr(), tex.data_ptr(), x_t.data_ptr(), out_idx.data_ptr()
+    a.temp, a.n_rows, a.n, a.C, a.n_class, a.n_heads = float(temp), int(n_rows), n, C, n_class, n_heads
+    check(_lib.load().t2h_sample_heads(ctypes.byref(a), _stream()), 't2h_sample_heads')
 
 
 def sample_head(hidden, lnf_g, lnf_b, w_head, expo, changes, tex, head, temp, x_t, out_idx):
