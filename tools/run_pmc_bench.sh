@@ -1,0 +1,15 @@
+#!/bin/bash
+# The three rocprofv3 --pmc passes behind profiles/r01_pmc_summary.* (one counter group per
+# pass, no tracing besides the kernel trace) over a shortened bench step.
+set -u
+REPO=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  name=pmc_$(echo $grp | cut -d' ' -f1)
+  rm -rf $REPO/gpurun_out/$name
+  timeout 300 rocprofv3 --pmc $grp -d $REPO/gpurun_out/$name -o p -- python $REPO/bench.py --steps 1 --warmup 1 \
+      --sample-steps 4 --no-cpu-baseline > $REPO/gpurun_out/$name.log 2>&1
+  echo "$name exit $?"
+  find $REPO/gpurun_out/$name -name 'p_results.db' -exec mv {} $REPO/gpurun_out/$name/p_results.db \; 2>/dev/null
+done
+cd $REPO && python tools/pmc_summary.py gpurun_out gpurun_out/pmc_summary_new
