@@ -204,11 +204,15 @@ __global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
     // fp32 rows and / or split rows (operand of the split-precision proj GEMM)
     const int64_t grow = (int64_t)b * T + q0;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c4);
-      if (y) *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c4) = v;
-      if (y_split) t2h_store_split4(y_split, grow + row, C, head * HD + c4, v);
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8 + 4);
+      if (y) {
+        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
+        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
+      }
+      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb);
     }
   }
 }
@@ -493,11 +497,15 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   if (kh == 0) {
     const int64_t grow = (int64_t)b * T + q0;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c4);
-      if (y) *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c4) = v;
-      if (y_split) t2h_store_split4(y_split, grow + row, C, head * HD + c4, v);
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8 + 4);
+      if (y) {
+        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
+        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
+      }
+      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb);
     }
   }
 #ifdef T2H_MHA_TIMING

@@ -79,6 +79,26 @@ __device__ __forceinline__ void t2h_split2(float x, _Float16& hi, _Float16& lo) 
   lo = (_Float16)((x - (float)hi) * T2H_SPLIT_LO_SCALE);
 }
 
+// writes 8 consecutive columns c0..c0+7 (c0 % 8 == 0) of `row` as split rows: one 16-byte
+// store per plane
+__device__ __forceinline__ void t2h_store_split8(uint16_t* base, int64_t row, int C, int c0, f32x4 va, f32x4 vb) {
+  t2h_f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    _Float16 a, b;
+    t2h_split2(va[e], a, b);
+    h[e] = a;
+    l[e] = b;
+    t2h_split2(vb[e], a, b);
+    h[4 + e] = a;
+    l[4 + e] = b;
+  }
+  char* d = reinterpret_cast<char*>(base) + row * (int64_t)(C / 32) * T2H_SPLIT_TILE_B +
+            (c0 >> 5) * T2H_SPLIT_TILE_B + (c0 & 31) * 2;
+  *reinterpret_cast<t2h_f16x8*>(d) = h;
+  *reinterpret_cast<t2h_f16x8*>(d + T2H_SPLIT_PLANE_B) = l;
+}
+
 // writes 4 consecutive columns c0..c0+3 (c0 % 4 == 0) of `row` as split rows
 __device__ __forceinline__ void t2h_store_split4(uint16_t* base, int64_t row, int C, int c0, f32x4 v) {
   t2h_f16x4 h, l;

@@ -78,6 +78,35 @@ __device__ __forceinline__ float gelu_erf_s(float v) {
   return 0.5f * v * (1.0f + erf_rational(v * 0.70710678118654752440f));
 }
 
+// the same on 4 values with the polynomial arithmetic on register pairs (v_pk_fma_f32)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_2(f32x2 v) {
+  f32x2 x = v * 0.70710678118654752440f;
+  x[0] = fminf(fmaxf(x[0], -4.0f), 4.0f);
+  x[1] = fminf(fmaxf(x[1], -4.0f), 4.0f);
+  const f32x2 x2 = x * x;
+  auto fma2 = [](f32x2 a, f32x2 b, float c) { return __builtin_elementwise_fma(a, b, f32x2{c, c}); };
+  f32x2 p = {-2.72614225801306e-10f, -2.72614225801306e-10f};
+  p = fma2(p, x2, 2.77068142495902e-08f);
+  p = fma2(p, x2, -2.10102402082508e-06f);
+  p = fma2(p, x2, -5.69250639462346e-05f);
+  p = fma2(p, x2, -7.34990630326855e-04f);
+  p = fma2(p, x2, -2.95459980854025e-03f);
+  p = fma2(p, x2, -1.60960333262415e-02f);
+  f32x2 q = {-1.45660718464996e-05f, -1.45660718464996e-05f};
+  q = fma2(q, x2, -2.13374055278905e-04f);
+  q = fma2(q, x2, -1.68282697438203e-03f);
+  q = fma2(q, x2, -7.37332916720468e-03f);
+  q = fma2(q, x2, -1.42647390514189e-02f);
+  const f32x2 rq = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  const f32x2 e = x * p * rq;
+  return (v * 0.5f) * (e + 1.0f);
+}
+__device__ __forceinline__ f32x4 gelu_erf_v(f32x4 v) {
+  const f32x2 a = gelu_erf_2(f32x2{v[0], v[1]}), b = gelu_erf_2(f32x2{v[2], v[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
+
 // KS = 2: in-block K split.  Two wave groups of WARPS_M x WARPS_N waves each own the
 // whole BM x BN tile, their own pair of LDS tile buffers and every second K tile (group
 // g takes tiles 2s + g); the partial sums meet in LDS in the epilogue, group 0 first, so
@@ -308,24 +337,40 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     }
     return;
   }
-  constexpr int CPR = WN / 4;              // float4 chunks per staged row
+  constexpr int CPR = WN / 8;              // 8-column chunks per staged row
   constexpr int NCH = WM * CPR / 64 / KS;  // chunks per lane (the K groups share the stores)
+  static_assert(NCH >= 1 && NCH * 64 * KS == WM * CPR, "epilogue chunking");
 #pragma unroll
   for (int it = 0; it < NCH; ++it) {
     const int c = lane + 64 * (it + kg * NCH);
-    const int rl = c / CPR, c4 = (c - rl * CPR) * 4;
-    const int row = m0 + wm0 + rl, col = n0 + wn0 + c4;
+    const int rl = c / CPR, c8 = (c - rl * CPR) * 8;
+    const int row = m0 + wm0 + rl, col = n0 + wn0 + c8;
     if (row >= p.M || col >= p.N) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c4);
-    if (KS == 2) v += *reinterpret_cast<const f32x4*>(Ot + NWG * WM * O_LD + rl * O_LD + c4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (p.epi_act == 1) v[e] = gelu_erf_s(v[e]);
-      else if (p.epi_act == 2) v[e] = fmaxf(v[e], 0.f);
+    f32x4 va = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8);
+    f32x4 vb = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8 + 4);
+    if (KS == 2) {
+      va += *reinterpret_cast<const f32x4*>(Ot + NWG * WM * O_LD + rl * O_LD + c8);
+      vb += *reinterpret_cast<const f32x4*>(Ot + NWG * WM * O_LD + rl * O_LD + c8 + 4);
     }
-    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
-    if (p.C) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
-    if (p.C_split) t2h_store_split4(p.C_split, row, p.N, col, v);
+    if (p.epi_act == 1) {
+      va = gelu_erf_v(va);
+      vb = gelu_erf_v(vb);
+    } else if (p.epi_act == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        va[e] = fmaxf(va[e], 0.f);
+        vb[e] = fmaxf(vb[e], 0.f);
+      }
+    }
+    if (p.residual) {
+      va += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
+      vb += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col + 4);
+    }
+    if (p.C) {
+      *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = va;
+      *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col + 4) = vb;
+    }
+    if (p.C_split) t2h_store_split8(p.C_split, row, p.N, col, va, vb);
   }
 }
 
@@ -370,9 +415,9 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
   T2H_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0, "t2h_gemm_split_f32: bad shape M=%d N=%d K=%d",
               a.M, a.N, a.K);
   T2H_REQUIRE(t2h_aligned16(a.A) && t2h_aligned16(a.B), "t2h_gemm_split_f32: operands must be 16-byte aligned");
-  T2H_REQUIRE(a.N % 4 == 0 && (!a.C || (a.ldc % 4 == 0 && t2h_aligned16(a.C))) &&
+  T2H_REQUIRE(a.N % 8 == 0 && (!a.C || (a.ldc % 4 == 0 && t2h_aligned16(a.C))) &&
                   (!a.residual || (a.ldr % 4 == 0 && t2h_aligned16(a.residual))),
-              "t2h_gemm_split_f32: N, ldc, ldr must be multiples of 4 and C / residual 16-byte aligned");
+              "t2h_gemm_split_f32: N must be a multiple of 8, ldc / ldr of 4, C / residual 16-byte aligned");
   if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
   if (a.Vt)
     T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 32 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&

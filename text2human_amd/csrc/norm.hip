@@ -43,8 +43,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-    if (SPLIT) t2h_store_split4(reinterpret_cast<uint16_t*>(y), row, C, i * 256 + lane * 4, o);
-    else *reinterpret_cast<f32x4*>(yr + i * 256 + lane * 4) = o;
+    if (!SPLIT) *reinterpret_cast<f32x4*>(yr + i * 256 + lane * 4) = o;
+    else v[i] = o;
+  }
+  if (SPLIT) {
+    // lanes 2j, 2j+1 hold columns 8j..8j+3 / 8j+4..8j+7 of every 256-column slab: they
+    // swap vectors so that each writes 8 consecutive columns (one 16-byte store per
+    // plane) -- the even lane slab i, the odd lane slab i+1
+    static_assert(VPL % 2 == 0 || VPL == 1, "pairwise slab exchange");
+    if (VPL == 1) {
+      t2h_store_split4(reinterpret_cast<uint16_t*>(y), row, C, lane * 4, v[0]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VPL; i += 2) {
+        const bool odd = lane & 1;
+        f32x4 send, recv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          send[e] = odd ? v[i][e] : v[i + 1][e];
+          recv[e] = __shfl_xor(send[e], 1, 64);
+        }
+        if (!odd) t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, i * 256 + lane * 4, v[i], recv);
+        else t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, (i + 1) * 256 + (lane - 1) * 4, recv, v[i + 1]);
+      }
+    }
   }
 }
 
