@@ -128,7 +128,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   constexpr int NMMA = 2 * 3 * TM * TN;  // MFMAs per wave and K tile
   constexpr int BUF_B = (BM + BN) * SP_LDS_ROW;  // bytes per LDS tile buffer: [A rows | B rows]
   constexpr int O_LD = WN + 4;                   // epilogue staging row (floats), odd # of 16-B slots
-  constexpr int EPI_B = WM * O_LD * 4 * NWG * KS;
+  constexpr int OT_LD = WM + 4;                  // transposed staging (value planes): floats per column
+  constexpr int OW = WM * O_LD > WN * OT_LD ? WM * O_LD : WN * OT_LD;  // staging floats per wave
+  constexpr int EPI_B = OW * 4 * NWG * KS;
   constexpr int SMEM_B = 2 * BUF_B * KS > EPI_B ? 2 * BUF_B * KS : EPI_B;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
@@ -285,8 +287,68 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   // lane owns 4 CONSECUTIVE columns of a row: residual loads and fp32 stores become
   // 16-byte accesses and a split-row store is three 8-byte writes instead of twelve
   // 2-byte ones.
-  float* const Ot = reinterpret_cast<float*>(smem) + wave * (WM * O_LD);  // group 0's staged wave tile
-  float* const Og = Ot + kg * (NWG * WM * O_LD);                           // this group's
+  float* const Ot = reinterpret_cast<float*>(smem) + wave * OW;  // group 0's staged wave tile
+  float* const Og = Ot + kg * (NWG * OW);                        // this group's
+  if (p.Vt != nullptr && n0 >= p.vt_col0) {
+    // Value heads of the q|k|v projection -> transposed planes Vt[B][H][2][hd][T].  The wave
+    // tile is staged TRANSPOSED ([column][row]: a lane's 4 consecutive accumulator registers
+    // are 4 consecutive rows = one 16-byte LDS write), then every lane takes one column and
+    // the 8 keys {16j + 4h + 0..3, 16j + 8 + 4h + 0..3} that the attention kernel contracts
+    // in one k16-step: they sit at the 8 consecutive positions 16j + 8h .. + 7 of the plane,
+    // so the store is one 16-byte piece per plane and contiguous across lanes.
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TN; ++tj) {
+        const int col = n0 + wn0 + tj * 32 + l31;
+        const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 w4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            w4[e] = fmaf(acc[1][ti][tj][4 * g4 + e], T2H_SPLIT_LO_INV, acc[0][ti][tj][4 * g4 + e]) + bv;
+          *reinterpret_cast<f32x4*>(Og + (tj * 32 + l31) * OT_LD + ti * 32 + 8 * g4 + 4 * hh) = w4;
+        }
+      }
+    __syncthreads();
+    constexpr int RG = WM / 8;                   // 8-key chunks per staged column
+    constexpr int NCV = RG * WN / 64 / KS;       // chunks per lane
+    static_assert(NCV >= 1 && NCV * 64 * KS == RG * WN, "value-plane chunking");
+    const int n_vh = (p.N - p.vt_col0) / p.vt_hd;
+    const int row0 = m0 + wm0;                   // first row of the wave tile (multiple of 32)
+    const int b = row0 / p.vt_T, key0 = row0 - b * p.vt_T;
+#pragma unroll
+    for (int it = 0; it < NCV; ++it) {
+      const int c = lane + 64 * (it + kg * NCV);
+      const int cl = c / RG, u = c - cl * RG;
+      const int col = n0 + wn0 + cl;
+      const int ra = 16 * (u >> 1) + 4 * (u & 1);  // rows ra..ra+3 and ra+8..ra+11
+      if (row0 + ra >= p.M || col >= p.N) continue;
+      f32x4 va = *reinterpret_cast<const f32x4*>(Ot + cl * OT_LD + ra);
+      f32x4 vb = *reinterpret_cast<const f32x4*>(Ot + cl * OT_LD + ra + 8);
+      if (KS == 2) {
+        va += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + cl * OT_LD + ra);
+        vb += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + cl * OT_LD + ra + 8);
+      }
+      t2h_f16x8 vh, vl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 x0, x1;
+        t2h_split2(va[e], x0, x1);
+        vh[e] = x0;
+        vl[e] = x1;
+        t2h_split2(vb[e], x0, x1);
+        vh[4 + e] = x0;
+        vl[4 + e] = x1;
+      }
+      const int cc = col - p.vt_col0, head = cc / p.vt_hd, d = cc - head * p.vt_hd;
+      uint16_t* dstp = p.Vt + ((((int64_t)b * n_vh + head) * 2) * p.vt_hd + d) * p.vt_T + key0 + 8 * u;
+      *reinterpret_cast<t2h_f16x8*>(dstp) = vh;
+      *reinterpret_cast<t2h_f16x8*>(dstp + (int64_t)p.vt_hd * p.vt_T) = vl;
+    }
+    return;
+  }
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
@@ -299,44 +361,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
             fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]) + bv;
     }
   __syncthreads();
-  if (p.Vt != nullptr && n0 >= p.vt_col0) {
-    // value heads of the q|k|v projection: transposed planes Vt[B][H][2][hd][T].  A chunk is
-    // one output column x 4 consecutive rows (= 4 consecutive keys, which stay adjacent
-    // under the key permutation); consecutive lanes take consecutive row groups, so a
-    // column's stores are contiguous 8-byte pieces per plane.
-    constexpr int RG = WM / 4;                   // row groups per staged column
-    constexpr int NCV = RG * WN / 64 / KS;       // chunks per lane
-    const int n_vh = (p.N - p.vt_col0) / p.vt_hd;
-#pragma unroll
-    for (int it = 0; it < NCV; ++it) {
-      const int c = lane + 64 * (it + kg * NCV);
-      const int cl = c / RG, r4 = (c - cl * RG) * 4;
-      const int row = m0 + wm0 + r4, col = n0 + wn0 + cl;
-      if (row >= p.M || col >= p.N) continue;
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = Ot[(r4 + e) * O_LD + cl];
-        if (KS == 2) v[e] += Ot[NWG * WM * O_LD + (r4 + e) * O_LD + cl];
-      }
-      const int b = row / p.vt_T, key = row - b * p.vt_T;
-      const int cc = col - p.vt_col0, head = cc / p.vt_hd, d = cc - head * p.vt_hd;
-      const int w = key & 31;
-      const int pos = (key & ~31) + 16 * (w >> 4) + 8 * ((w >> 2) & 1) + 4 * ((w >> 3) & 1);
-      t2h_f16x4 vh, vl;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        _Float16 x0, x1;
-        t2h_split2(v[e], x0, x1);
-        vh[e] = x0;
-        vl[e] = x1;
-      }
-      uint16_t* dstp = p.Vt + ((((int64_t)b * n_vh + head) * 2) * p.vt_hd + d) * p.vt_T + pos;
-      *reinterpret_cast<t2h_f16x4*>(dstp) = vh;
-      *reinterpret_cast<t2h_f16x4*>(dstp + (int64_t)p.vt_hd * p.vt_T) = vl;
-    }
-    return;
-  }
   constexpr int CPR = WN / 8;              // 8-column chunks per staged row
   constexpr int NCH = WM * CPR / 64 / KS;  // chunks per lane (the K groups share the stores)
   static_assert(NCH >= 1 && NCH * 64 * KS == WM * CPR, "epilogue chunking");
@@ -349,8 +373,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     f32x4 va = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8);
     f32x4 vb = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8 + 4);
     if (KS == 2) {
-      va += *reinterpret_cast<const f32x4*>(Ot + NWG * WM * O_LD + rl * O_LD + c8);
-      vb += *reinterpret_cast<const f32x4*>(Ot + NWG * WM * O_LD + rl * O_LD + c8 + 4);
+      va += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + rl * O_LD + c8);
+      vb += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + rl * O_LD + c8 + 4);
     }
     if (p.epi_act == 1) {
       va = gelu_erf_v(va);
@@ -420,7 +444,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
               "t2h_gemm_split_f32: N must be a multiple of 8, ldc / ldr of 4, C / residual 16-byte aligned");
   if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
   if (a.Vt)
-    T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 32 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&
+    T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 128 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&
                     a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,
                 "t2h_gemm_split_f32: bad Vt routing (col0=%d T=%d hd=%d M=%d N=%d)", a.vt_col0, a.vt_T, a.vt_hd,
                 a.M, a.N);
