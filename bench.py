@@ -182,6 +182,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         finally:
+            # the banner goes through C stdio, which block-buffers when stdout is a pipe and
+            # would otherwise flush it to the restored fd 1 at exit: drain it to stderr now
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
