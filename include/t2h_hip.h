@@ -225,6 +225,17 @@ int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream);
 int t2h_vq_l2_argmin_f32(const float* z, const float* codebook, int64_t* idx,
                          int32_t n, int32_t n_e, int32_t d, void* stream);
 
+/* Encode side: texture-routed quantisation.  VectorQuantizerTexture.forward
+ * (vqgan_arch.py:232-268; fold_h = fold_w = 0, z = [n, d] latent rows) and
+ * VectorQuantizerSpatialTextureAware.forward (:392-443; z = NHWC map
+ * [n / (fold_h fold_w), 2 fold_h, 2 fold_w, d / 4], row (b, i, j) = its 2x2 patch in
+ * F.unfold layout [c, kh, kw]).  idx_lists[tex[row]][row] = argmin_j |z - books[tex[row]][j]|^2
+ * (expanded form, first minimum wins), every other idx_lists[h][row] = -1.
+ * books: [n_books][n_e][d]; d in {256, 1024}. */
+int t2h_vq_argmin_tex_f32(const float* z, const float* books, const int64_t* tex, int64_t* idx_lists,
+                          int32_t n, int32_t n_books, int32_t n_e, int32_t d, int32_t fold_h,
+                          int32_t fold_w, void* stream);
+
 /* VectorQuantizerTexture.get_codebook_entry, vqgan_arch.py:289-309:
  * out[row, :] = books[tex[row]][idx[tex[row]][row]]  (idx_lists: [18, n]) */
 int t2h_codebook_gather_tex_f32(const int64_t* idx_lists, const int64_t* tex,

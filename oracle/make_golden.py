@@ -39,7 +39,7 @@ def moments(t):
 def golden_inputs(name):
     """Seeded inputs shared by make_golden and the tests."""
     g = torch.Generator().manual_seed({'decoder': 100, 'transformer': 101,
-                                       'unet': 102}[name])
+                                       'unet': 102, 'encode': 103}[name])
     if name == 'decoder':
         return dict(z=torch.randn(1, 256, 32, 16, generator=g) * 0.05,
                     zb=torch.randn(1, 256, 64, 32, generator=g) * 0.05)
@@ -49,6 +49,9 @@ def golden_inputs(name):
                     tex=torch.randint(0, 18, (1, 512), generator=g))
     if name == 'unet':
         return dict(x=torch.randn(2, 256, 32, 16, generator=g) * 0.1)
+    if name == 'encode':
+        return dict(image=torch.rand(1, 3, 512, 256, generator=g) * 2 - 1,
+                    texture_mask=synthetic.parsing_batch(1, seed=2021)['texture_mask'])
     raise KeyError(name)
 
 
@@ -56,10 +59,72 @@ TRANSFORMER_ROWS = [0, 1, 77, 300, 511]
 TRANSFORMER_HEADS = [0, 5, 11, 17]
 
 
+def _routed_margin(zf, tex, books):
+    """per row: (second best - best) expanded L2 distance inside the row's own codebook"""
+    out = torch.zeros(zf.shape[0])
+    for cb in range(18):
+        sel = tex == cb
+        if sel.any():
+            e = books[f'embedding_list.{cb}.weight']
+            d = (zf[sel]**2).sum(1, keepdim=True) + (e**2).sum(1) - 2 * zf[sel] @ e.t()
+            t2 = d.topk(2, dim=1, largest=False).values
+            out[sel] = t2[:, 1] - t2[:, 0]
+    return out
+
+
+def make_encode_golden(ns, opt):
+    """Encode side: reference Encoder / quantizer modules,
+    encode-mode synthetic weights (codebooks U(+-1)), one image."""
+    V = ns.vqgan_arch
+    sds = synthetic.make_state_dicts(opt, seed=WEIGHT_SEED, encode=True)
+    mk = lambda cm, ar, key: _load(quiet(V.Encoder, ch=128, num_res_blocks=2, attn_resolutions=ar, ch_mult=cm,
+                                         in_channels=3, resolution=512, z_channels=256, double_z=False,
+                                         dropout=0.0).eval(), sds[key])
+    top_enc, bot_enc = mk([1, 1, 2, 2, 4], [32], 'top_encoder'), mk([1, 1, 2, 4], [64], 'bot_encoder')
+    top_q = _load(quiet(V.VectorQuantizerTexture, 1024, 256, beta=0.25).eval(), sds['top_quantize'])
+    bot_q = _load(quiet(V.VectorQuantizerSpatialTextureAware, 512, 256, beta=0.25, spatial_size=2).eval(),
+                  sds['bot_quantize'])
+    dec = _load(quiet(V.Decoder, in_channels=3, resolution=512, z_channels=256, ch=128, out_ch=3,
+                      num_res_blocks=2, attn_resolutions=[32], ch_mult=[1, 1, 2, 2, 4], dropout=0.0).eval(),
+                sds['decoder'])
+    res = _load(quiet(V.DecoderRes, in_channels=3, resolution=512, z_channels=256, ch=128, num_res_blocks=2,
+                      ch_mult=[1, 1, 2, 4], dropout=0.0).eval(), sds['bot_decoder_res'])
+    conv = lambda sd: (lambda x: F.conv2d(x, sd['weight'], sd['bias']))
+    gi = golden_inputs('encode')
+    img, mask = gi['image'], gi['texture_mask']
+    h = conv(sds['top_quant_conv'])(top_enc(img))
+    zq, _, (_, _, top_idx) = top_q(h, mask)
+    quant_t = conv(sds['top_post_quant_conv'])(zq)
+    hb = conv(sds['bot_quant_conv'])(bot_enc(img))
+    zqb, _, (_, _, bot_idx) = bot_q(hb, mask)
+    rec = dec(quant_t, bot_h=res(conv(sds['bot_post_quant_conv'])(zqb)))
+    tex = F.interpolate(mask, (32, 16), mode='nearest').view(-1)
+    top_margin = _routed_margin(h.permute(0, 2, 3, 1).reshape(-1, 256), tex, sds['top_quantize'])
+    patches = F.unfold(hb, (2, 2), stride=2).permute(0, 2, 1).reshape(-1, 1024)
+    bot_margin = _routed_margin(patches, tex, sds['bot_quantize'])
+    np.savez_compressed(
+        os.path.join(OUT, 'encode_b1.npz'),
+        top_indices=torch.stack(top_idx).numpy().astype(np.int16),
+        bot_indices=torch.stack(bot_idx).numpy().astype(np.int16),
+        top_margin=top_margin.numpy(), bot_margin=bot_margin.numpy(),
+        top_latent_sample=h[0, ::8, ::2, ::2].numpy(), bot_latent_sample=hb[0, ::8, ::4, ::4].numpy(),
+        quant_t_sample=quant_t[0, ::8, ::2, ::2].numpy(),
+        rec_sample=rec[0, :, ::4, ::4].numpy(), rec_moments=moments(rec))
+
+
+def _load(module, sd):
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load_reference('cpu')
     opt = options.dict_to_nonedict(defaults.sample_from_pose())
+    torch.set_grad_enabled(False)
+    make_encode_golden(ns, opt)
+    if os.environ.get('T2H_GOLDEN_ONLY') == 'encode':
+        return
     sds = synthetic.make_state_dicts(opt, seed=WEIGHT_SEED)
     V = ns.vqgan_arch
     torch.set_grad_enabled(False)

@@ -202,6 +202,90 @@ def bot_codebook_entry(indices_list, texture_mask, books_sd, shape_hw=(32, 16),
                   (h * spatial, w * spatial), kernel_size=spatial, stride=spatial)
 
 
+# ---------------------------------------------------------------- encode side
+# (image -> tokens; hierarchy_inference_model.py:170-197)
+
+
+def texture_vq_forward(z, texture_mask, books_sd):
+    """VectorQuantizerTexture.forward, vqgan_arch.py:212-287: every latent pixel is
+    quantised with the codebook of its (nearest-resized) texture id.
+    z f32 [B, C, h, w] -> (z_q f32 [B, C, h, w], 18 x i64 [B, h, w], -1 off-texture)."""
+    b, c, h, w = z.shape
+    tex = F.interpolate(texture_mask, (h, w), mode='nearest').view(-1)
+    zf = z.permute(0, 2, 3, 1).reshape(-1, c)
+    zq = torch.zeros_like(zf)
+    idx_lists = []
+    for cb in range(18):
+        idx = torch.full((tex.numel(), ), -1, dtype=torch.long)
+        sel = tex == cb
+        if sel.any():
+            book = books_sd[f'embedding_list.{cb}.weight']
+            found = vq_l2_argmin(zf[sel], book)
+            zq[sel] = book[found]
+            idx[sel] = found
+        idx_lists.append(idx.view(b, h, w))
+    return zq.view(b, h, w, c).permute(0, 3, 1, 2).contiguous(), idx_lists
+
+
+def spatial_texture_vq_forward(z, texture_mask, books_sd, spatial=2):
+    """VectorQuantizerSpatialTextureAware.forward, vqgan_arch.py:375-461: the latent is cut
+    into spatial x spatial patches (F.unfold, entry layout [c, kh, kw]) and every patch is
+    quantised with the codebook of its texture id.
+    z f32 [B, C, H, W] -> (z_q f32 [B, C, H, W], 18 x i64 [B, H/s, W/s])."""
+    b, c, hh, ww = z.shape
+    h, w = hh // spatial, ww // spatial
+    tex = F.interpolate(texture_mask, (h, w), mode='nearest').view(-1)
+    patches = F.unfold(z, (spatial, spatial), stride=spatial).permute(0, 2, 1)  # [B, h*w, C*s*s]
+    pf = patches.reshape(-1, c * spatial * spatial)
+    zq = torch.zeros_like(pf)
+    idx_lists = []
+    for cb in range(18):
+        idx = torch.full((tex.numel(), ), -1, dtype=torch.long)
+        sel = tex == cb
+        if sel.any():
+            book = books_sd[f'embedding_list.{cb}.weight']
+            found = vq_l2_argmin(pf[sel], book)
+            zq[sel] = book[found]
+            idx[sel] = found
+        idx_lists.append(idx.view(b, h, w))
+    zq = F.fold(zq.view(patches.shape).permute(0, 2, 1), (hh, ww), kernel_size=spatial, stride=spatial)
+    return zq, idx_lists
+
+
+def top_encode(image, texture_mask, sds):
+    """top_encode, hierarchy_inference_model.py:170-176: Encoder -> 1x1 quant_conv ->
+    texture-routed VQ -> 1x1 post_quant_conv.  Returns (quant_t [B,256,32,16], idx lists)."""
+    hcur = encoder(image, sds['top_encoder'])
+    hcur = F.conv2d(hcur, sds['top_quant_conv']['weight'], sds['top_quant_conv']['bias'])
+    zq, idx_lists = texture_vq_forward(hcur, texture_mask, sds['top_quantize'])
+    quant = F.conv2d(zq, sds['top_post_quant_conv']['weight'], sds['top_post_quant_conv']['bias'])
+    return quant, idx_lists
+
+
+def bot_encode(image, texture_mask, sds, spatial=2):
+    """bot_encode, hierarchy_inference_model.py:187-192: the 18 bottom index maps."""
+    hcur = encoder(image, sds['bot_encoder'])
+    hcur = F.conv2d(hcur, sds['bot_quant_conv']['weight'], sds['bot_quant_conv']['bias'])
+    _, idx_lists = spatial_texture_vq_forward(hcur, texture_mask, sds['bot_quantize'], spatial)
+    return idx_lists
+
+
+def index_to_image(quant_t, bot_idx_lists, texture_mask, sds):
+    """index_to_image, hierarchy_inference_model.py:198-209."""
+    b, h, w = bot_idx_lists[0].shape
+    qb = bot_codebook_entry([i.view(b, -1) for i in bot_idx_lists], texture_mask, sds['bot_quantize'], (h, w))
+    qb = F.conv2d(qb, sds['bot_post_quant_conv']['weight'], sds['bot_post_quant_conv']['bias'])
+    return decoder(quant_t, sds['decoder'], bot_h=decoder_res(qb, sds['bot_decoder_res']))
+
+
+def reconstruct(image, texture_mask, sds):
+    """get_gt_indices + index_to_image: image -> (top, bottom) tokens -> image."""
+    quant_t, top_idx = top_encode(image, texture_mask, sds)
+    bot_idx = bot_encode(image, texture_mask, sds)
+    return index_to_image(quant_t, bot_idx, texture_mask, sds), dict(
+        quant_t=quant_t, top_indices=top_idx, bot_indices=bot_idx)
+
+
 # ---------------------------------------------------------------- transformer
 
 

@@ -184,3 +184,39 @@ def test_texture_map_rule(ns):
     m = R.texture_map(segm, up, lo, ou)
     m2 = synthetic.texture_mask_from_segm(segm.float(), up, lo, ou)
     assert torch.equal(m, m2)
+
+
+def test_encode_side_matches_reference_modules(ns, opt):
+    """top / bottom Encoder + texture-routed quantizers
+    (hierarchy_inference_model.py:170-192) -- indices exact, latents / image to rounding."""
+    V = ns.vqgan_arch
+    sds = synthetic.make_state_dicts(opt, seed=1234, encode=True)
+    top_enc = _quiet(V.Encoder, ch=128, num_res_blocks=2, attn_resolutions=[32], ch_mult=[1, 1, 2, 2, 4],
+                     in_channels=3, resolution=512, z_channels=256, double_z=False, dropout=0.0).eval()
+    top_enc.load_state_dict(sds['top_encoder'], strict=True)
+    bot_enc = _quiet(V.Encoder, ch=128, num_res_blocks=2, attn_resolutions=[64], ch_mult=[1, 1, 2, 4],
+                     in_channels=3, resolution=512, z_channels=256, double_z=False, dropout=0.0).eval()
+    bot_enc.load_state_dict(sds['bot_encoder'], strict=True)
+    top_q = _quiet(V.VectorQuantizerTexture, 1024, 256, beta=0.25).eval()
+    top_q.load_state_dict(sds['top_quantize'], strict=True)
+    bot_q = _quiet(V.VectorQuantizerSpatialTextureAware, 512, 256, beta=0.25, spatial_size=2).eval()
+    bot_q.load_state_dict(sds['bot_quantize'], strict=True)
+    conv = lambda sd: (lambda x: torch.nn.functional.conv2d(x, sd['weight'], sd['bias']))
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(1, 3, 512, 256, generator=g) * 2 - 1
+    mask = synthetic.parsing_batch(1, seed=2021)['texture_mask']
+    with torch.no_grad():
+        h = conv(sds['top_quant_conv'])(top_enc(img))
+        zq, _, (_, _, ref_top) = top_q(h, mask)
+        ref_quant_t = conv(sds['top_post_quant_conv'])(zq)
+        hb = conv(sds['bot_quant_conv'])(bot_enc(img))
+        zqb, _, (_, _, ref_bot) = bot_q(hb, mask)
+        quant_t, top_idx = R.top_encode(img, mask, sds)
+        bot_idx = R.bot_encode(img, mask, sds)
+        zq_o, _ = R.spatial_texture_vq_forward(hb, mask, sds['bot_quantize'])
+    for a, b in zip(ref_top, top_idx):
+        assert torch.equal(a, b)
+    for a, b in zip(ref_bot, bot_idx):
+        assert torch.equal(a, b)
+    _close(quant_t, ref_quant_t, 1e-5)
+    _close(zq_o, zqb, 1e-6)

@@ -83,6 +83,81 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
   }
 }
 
+// Texture-routed L2-argmin of the encode side: VectorQuantizerTexture.forward
+// (vqgan_arch.py:232-268) and, with fold, VectorQuantizerSpatialTextureAware.forward
+// (:392-443).  One wave per latent row; the row is quantised with the codebook of its own
+// texture id (expanded distance sum z^2 + sum e^2 - 2 z.e, first minimum wins), all other
+// heads get -1.  EPL float4 per lane: D = 256 * EPL.  With fold the row is the 2x2 patch
+// (i, j) of an NHWC map in F.unfold layout [c, kh, kw]: lane element c*4 + (2 kh + kw).
+template <int EPL>
+__global__ __launch_bounds__(256) void vq_argmin_tex_kernel(const float* __restrict__ z,
+                                                            const float* __restrict__ books,
+                                                            const int64_t* __restrict__ tex,
+                                                            int64_t* __restrict__ idx_lists, int n, int n_books,
+                                                            int n_e, int fh, int fw) {
+  constexpr int D = 256 * EPL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= n) return;
+  const int t = (int)tex[row];
+  for (int hd = lane; hd < n_books; hd += 64)
+    if (hd != t) idx_lists[(int64_t)hd * n + row] = -1;
+  if (t < 0 || t >= n_books) return;
+  f32x4 zv[EPL];
+  if (fh > 0) {
+    const int C = D / 4;
+    const int b = row / (fh * fw), rem = row - b * fh * fw;
+    const int i = rem / fw, j = rem - i * fw;
+#pragma unroll
+    for (int m = 0; m < EPL; ++m) {
+      const int c = m * 64 + lane;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        zv[m][e] = z[(((int64_t)b * 2 * fh + 2 * i + (e >> 1)) * 2 * fw + 2 * j + (e & 1)) * C + c];
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < EPL; ++m) zv[m] = *reinterpret_cast<const f32x4*>(z + (int64_t)row * D + (m * 64 + lane) * 4);
+  }
+  float zz = 0.f;
+#pragma unroll
+  for (int m = 0; m < EPL; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) zz = fmaf(zv[m][e], zv[m][e], zz);
+  zz = wave_sum(zz);
+  const float* book = books + (int64_t)t * n_e * D;
+  float best = INFINITY;
+  int best_j = 0;
+  for (int j0 = 0; j0 < n_e; j0 += 4) {
+    float dot[4], ee[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* er = book + (int64_t)min(j0 + u, n_e - 1) * D;
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int m = 0; m < EPL; ++m) {
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(er + (m * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a = fmaf(zv[m][e], ev[e], a);
+          q = fmaf(ev[e], ev[e], q);
+        }
+      }
+      dot[u] = a;
+      ee[u] = q;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float d = (zz + wave_sum(ee[u])) - 2.0f * wave_sum(dot[u]);
+      if (j0 + u < n_e && d < best) {
+        best = d;
+        best_j = j0 + u;
+      }
+    }
+  }
+  if (lane == 0) idx_lists[(int64_t)t * n + row] = best_j;
+}
+
 __global__ void gather_tex_kernel(const int64_t* __restrict__ idx_lists, const int64_t* __restrict__ tex,
                                   const float* __restrict__ books, float* __restrict__ out, int n,
                                   int n_e, int e_dim) {
@@ -219,5 +294,27 @@ extern "C" int t2h_routed_head_argmax(const float* feat, int32_t ldf, const floa
                      static_cast<hipStream_t>(stream), feat, ldf, w, b, tex, out_lists, n, n_heads, Cf,
                      n_class);
   T2H_CHECK_LAUNCH("t2h_routed_head_argmax");
+  return T2H_OK;
+}
+
+extern "C" int t2h_vq_argmin_tex_f32(const float* z, const float* books, const int64_t* tex, int64_t* idx_lists,
+                                     int32_t n, int32_t n_books, int32_t n_e, int32_t d, int32_t fold_h,
+                                     int32_t fold_w, void* stream) {
+  T2H_REQUIRE(z && books && tex && idx_lists, "t2h_vq_argmin_tex_f32: NULL pointer");
+  T2H_REQUIRE(n > 0 && n_books > 0 && n_e > 0, "t2h_vq_argmin_tex_f32: empty problem");
+  T2H_REQUIRE((fold_h > 0) == (fold_w > 0) && (fold_h == 0 || n % (fold_h * fold_w) == 0),
+              "t2h_vq_argmin_tex_f32: bad fold shape %d x %d for n=%d", fold_h, fold_w, n);
+  T2H_REQUIRE(t2h_aligned16(z) && t2h_aligned16(books), "t2h_vq_argmin_tex_f32: 16-byte alignment");
+  dim3 grid((n + 3) / 4), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d == 256)
+    hipLaunchKernelGGL(vq_argmin_tex_kernel<1>, grid, block, 0, s, z, books, tex, idx_lists, n, n_books, n_e, fold_h, fold_w);
+  else if (d == 1024)
+    hipLaunchKernelGGL(vq_argmin_tex_kernel<4>, grid, block, 0, s, z, books, tex, idx_lists, n, n_books, n_e, fold_h, fold_w);
+  else {
+    t2h_set_error("t2h_vq_argmin_tex_f32: d=%d unsupported (256 / 1024)", d);
+    return T2H_ERR_UNSUPPORTED;
+  }
+  T2H_CHECK_LAUNCH("t2h_vq_argmin_tex_f32");
   return T2H_OK;
 }

@@ -1,13 +1,16 @@
 """`create_model(opt)` factory -- drop-in for the reference's
-models/__init__.py:21-42 restricted to the two sampling model types."""
+models/__init__.py:21-42 restricted to the two sampling model types and the
+inference subset of the hierarchy (encode side) model."""
 import logging
 
+from .hierarchy_model import VQGANTextureAwareSpatialHierarchyInferenceModel
 from .sample_model import (BaseSampleModel, SampleFromParsingModel,  # noqa: F401
                            SampleFromPoseModel)
 
 _MODELS = {
     'SampleFromParsingModel': SampleFromParsingModel,
     'SampleFromPoseModel': SampleFromPoseModel,
+    'VQGANTextureAwareSpatialHierarchyInferenceModel': VQGANTextureAwareSpatialHierarchyInferenceModel,
 }
 
 

@@ -429,6 +429,24 @@ def vq_l2_argmin(z, codebook):
     return idx
 
 
+def vq_argmin_tex(z, books, tex, fold_hw=None):
+    """Texture-routed codebook argmin (encode side).  z: latent rows [n, d], or with
+    fold_hw=(h, w) the NHWC map rows [B*2h*2w, d/4] whose 2x2 patches are quantised;
+    books [n_books, n_e, d]; tex int64 [n].  Returns idx_lists int64 [n_books, n] (-1
+    where the row is not of that texture)."""
+    _chk_f32(z, books)
+    _chk_i64(tex)
+    nb, n_e, d = books.shape
+    n = tex.numel()
+    fh, fw = fold_hw or (0, 0)
+    assert z.is_contiguous() and books.is_contiguous()
+    assert z.numel() == n * d, (tuple(z.shape), n, d)
+    out = torch.empty((nb, n), device=z.device, dtype=torch.int64)
+    check(_lib.load().t2h_vq_argmin_tex_f32(_p(z), _p(books), _p(tex), _p(out), n, nb, n_e, d, fh, fw,
+                                            _stream()), 't2h_vq_argmin_tex_f32')
+    return out
+
+
 def codebook_gather_tex(idx_lists, tex, books):
     """idx_lists [18, n] i64, tex [n] i64, books [18, n_e, e_dim] -> [n, e_dim]."""
     _chk_i64(idx_lists, tex)

@@ -138,10 +138,11 @@ def encoder_schema(ch, ch_mult, num_res_blocks, attn_resolutions, in_channels,
     return sd
 
 
-def codebook_list_schema(n_e, e_dim, n_books=18):
+def codebook_list_schema(n_e, e_dim, n_books=18, spread=None):
+    """spread None = the constructors' U(+-1/n_e) (vqgan_arch.py:169,358)."""
     sd = OrderedDict()
     for i in range(n_books):
-        sd[f'embedding_list.{i}.weight'] = ((n_e, e_dim), ('uniform', 1.0 / n_e))
+        sd[f'embedding_list.{i}.weight'] = ((n_e, e_dim), ('uniform', spread or 1.0 / n_e))
     return sd
 
 
@@ -265,22 +266,28 @@ def fill(schema, seed):
     return out
 
 
-def module_schemas(opt):
-    """All state_dict schemas the sampling path consumes, keyed like App. B."""
+def module_schemas(opt, encode=False):
+    """All state_dict schemas the sampling path consumes, keyed like App. B.
+
+    encode=True adds the encode side of the hierarchy (top / bottom
+    Encoder + quant_conv, hierarchy_inference_model.py:28-37,63-87) and draws the texture
+    codebooks with a trained-like spread U(+-1) so that the L2-argmin is decided far above
+    fp32 rounding (the segm codebook below does the same)."""
     s = OrderedDict()
+    cb_spread = 1.0 if encode else None
     s['decoder'] = decoder_schema(opt['top_ch'], opt['top_ch_mult'],
                                   opt['top_num_res_blocks'],
                                   opt['top_attn_resolutions'],
                                   opt['top_resolution'], opt['top_z_channels'],
                                   opt['top_out_ch'])
-    s['top_quantize'] = codebook_list_schema(1024, opt['embed_dim'])
+    s['top_quantize'] = codebook_list_schema(1024, opt['embed_dim'], spread=cb_spread)
     s['top_post_quant_conv'] = OrderedDict()
     _conv(s['top_post_quant_conv'], '', opt['top_z_channels'], opt['embed_dim'], 1)
     s['bot_decoder_res'] = decoder_res_schema(opt['bot_ch'], opt['bot_ch_mult'],
                                               opt['bot_z_channels'])
     sp = opt['bot_codebook_spatial_size']
     s['bot_quantize'] = codebook_list_schema(opt['bot_n_embed'],
-                                             opt['embed_dim'] * sp * sp)
+                                             opt['embed_dim'] * sp * sp, spread=cb_spread)
     s['bot_post_quant_conv'] = OrderedDict()
     _conv(s['bot_post_quant_conv'], '', opt['bot_z_channels'], opt['embed_dim'], 1)
     s['segm_encoder'] = encoder_schema(opt['segm_ch'], opt['segm_ch_mult'],
@@ -316,7 +323,19 @@ def module_schemas(opt):
         s['shape_decoder'] = fcn_head_schema(opt['shape_fc_in_channels'],
                                              opt['shape_fc_channels'],
                                              opt['shape_fc_num_classes'])
-    for k in ('top_post_quant_conv', 'bot_post_quant_conv', 'segm_quant_conv'):
+    one_by_one = ['top_post_quant_conv', 'bot_post_quant_conv', 'segm_quant_conv']
+    if encode:
+        s['top_encoder'] = encoder_schema(opt['top_ch'], opt['top_ch_mult'], opt['top_num_res_blocks'],
+                                          opt['top_attn_resolutions'], opt['top_in_channels'],
+                                          opt['top_resolution'], opt['top_z_channels'], opt['top_double_z'])
+        s['bot_encoder'] = encoder_schema(opt['bot_ch'], opt['bot_ch_mult'], opt['bot_num_res_blocks'],
+                                          opt['bot_attn_resolutions'], opt['bot_in_channels'],
+                                          opt['bot_resolution'], opt['bot_z_channels'], opt['bot_double_z'])
+        for k, zc in (('top_quant_conv', opt['top_z_channels']), ('bot_quant_conv', opt['bot_z_channels'])):
+            s[k] = OrderedDict()
+            _conv(s[k], '', opt['embed_dim'], zc, 1)
+            one_by_one.append(k)
+    for k in one_by_one:
         s[k] = OrderedDict((n.lstrip('.'), v) for n, v in s[k].items())
     return s
 
@@ -325,16 +344,17 @@ _SEEDS = dict(decoder=11, top_quantize=12, top_post_quant_conv=13,
               bot_decoder_res=21, bot_quantize=22, bot_post_quant_conv=23,
               segm_encoder=31, segm_quantizer=32, segm_quant_conv=33,
               guidance_encoder=41, index_decoder=42, sampler=51,
-              shape_embedder=61, shape_encoder=62, shape_decoder=63)
+              shape_embedder=61, shape_encoder=62, shape_decoder=63,
+              top_encoder=71, top_quant_conv=72, bot_encoder=73, bot_quant_conv=74)
 
 
-def make_state_dicts(opt, seed=1234, head_scale=1.0, argmax_scale=1.0):
+def make_state_dicts(opt, seed=1234, head_scale=1.0, argmax_scale=1.0, encode=False):
     """Dict module-name -> state_dict (fp32 CPU tensors).
 
     head_scale / argmax_scale multiply the sampler heads / index-prediction
     heads to get peaked logits ("peaked-logits variant")."""
     sds = OrderedDict()
-    for name, schema in module_schemas(opt).items():
+    for name, schema in module_schemas(opt, encode=encode).items():
         sds[name] = fill(schema, seed * 1000 + _SEEDS[name])
     if head_scale != 1.0:
         for k in sds['sampler']:
@@ -369,6 +389,9 @@ def write_checkpoints(opt, out_dir, seed=1234, **kw):
             index_decoder=sds['index_decoder'])),
         'pretrained_sampler': ('sampler.pth', sds['sampler']),
     }
+    if 'top_encoder' in sds:  # encode side: the real checkpoints carry these keys too
+        files['top_vae_path'][1].update(encoder=sds['top_encoder'], quant_conv=sds['top_quant_conv'])
+        files['bot_vae_path'][1].update(bot_encoder=sds['bot_encoder'], bot_quant_conv=sds['bot_quant_conv'])
     if 'shape_embedder' in sds:
         files['pretrained_parsing_gen'] = ('parsing_gen.pth', dict(
             embedder=sds['shape_embedder'], encoder=sds['shape_encoder'],

@@ -278,12 +278,12 @@ def stack_codebooks(sd):
     return torch.stack([sd[f'embedding_list.{i}.weight'] for i in range(n)], 0)
 
 
-def load_checkpoints(opt, map_location='cpu'):
+def load_checkpoints(opt, map_location='cpu', encode=False):
     """Reads the `.pth` files named by the YAML exactly like
     BaseSampleModel.load_* (models/sample_model.py:124-181,397-410), including
     the fact that the bottom checkpoint's `decoder` overrides the top one's.
     Returns dict module-name -> state_dict and validates every one strictly."""
-    schemas = synthetic.module_schemas(opt)
+    schemas = synthetic.module_schemas(opt, encode=encode)
     top = torch.load(opt['top_vae_path'], map_location=map_location, weights_only=False)
     bot = torch.load(opt['bot_vae_path'], map_location=map_location, weights_only=False)
     seg = torch.load(opt['segm_token_path'], map_location=map_location, weights_only=False)
@@ -297,6 +297,9 @@ def load_checkpoints(opt, map_location='cpu'):
         segm_quant_conv=seg['quant_conv'], guidance_encoder=ipn['guidance_encoder'],
         index_decoder=ipn['index_decoder'], sampler=smp)
     check_state_dict(top['decoder'], schemas['decoder'], 'Decoder')  # loaded first, then overridden
+    if encode:  # hierarchy_inference_model.py:126-161
+        sds.update(top_encoder=top['encoder'], top_quant_conv=top['quant_conv'],
+                   bot_encoder=bot['bot_encoder'], bot_quant_conv=bot['bot_quant_conv'])
     if opt.get('pretrained_parsing_gen') and 'shape_embedder' in schemas:
         pg = torch.load(opt['pretrained_parsing_gen'], map_location=map_location, weights_only=False)
         sds.update(shape_embedder=pg['embedder'], shape_encoder=pg['encoder'],
