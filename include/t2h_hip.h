@@ -124,6 +124,18 @@ typedef struct t2h_gemm_split_args {
    * P*V matrix instruction contracts them.  NULL = off. */
   uint16_t* Vt;
   int32_t vt_col0, vt_T, vt_hd;
+  /* LayerNorm folded around the Linear (nn.LayerNorm + nn.Linear of Block.forward,
+   * transformer_arch.py:93-98).  Producer side, ln_part_out != NULL: also writes, per output
+   * row and 32-column slab, (sum, sum of squares) of the FINAL values to
+   * ln_part_out[M][N/32][2].  Consumer side, ln_part != NULL: A holds the un-normalised rows,
+   * B the weights scaled by gamma, bias = b + W beta, ln_colsum[j] = sum_k B[j][k]; the kernel
+   * returns rstd_i (acc_ij - mean_i ln_colsum[j]) + bias[j] with mean / rstd over K from the
+   * ln_parts partials of row i (eps = ln_eps), i.e. Linear(LayerNorm(x)). */
+  const float* ln_part;
+  const float* ln_colsum;
+  float* ln_part_out;
+  int32_t ln_parts;
+  float ln_eps;
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);

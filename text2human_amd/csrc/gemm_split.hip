@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   constexpr int EPI_B = OW * 4 * NWG * KS;
   constexpr int SMEM_B = 2 * BUF_B * KS > EPI_B ? 2 * BUF_B * KS : EPI_B;
 
-  __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_B + BM * 8];  // + (mean, rstd) of the BM rows
 
   const int kg = KS == 1 ? 0 : (int)threadIdx.x / NT;  // K group
   const int tid = threadIdx.x - kg * NT;
@@ -184,6 +184,20 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #pragma unroll
     for (int i = 0; i < L; ++i) gload16_async(rg[S][i], src[i] + k0);
   };
+
+  // folded LayerNorm: the row partials are summed (fixed order) up front, under the first
+  // tile loads, and turned into (mean, rstd) after the main loop
+  const bool ln_in = p.ln_part != nullptr;
+  float ln_su = 0.f, ln_sq = 0.f;
+  if (ln_in && (int)threadIdx.x < BM) {
+    const float2* pp =
+        reinterpret_cast<const float2*>(p.ln_part) + (int64_t)min(m0 + (int)threadIdx.x, p.M - 1) * p.ln_parts;
+    for (int i = 0; i < p.ln_parts; ++i) {
+      const float2 v = pp[i];
+      ln_su += v.x;
+      ln_sq += v.y;
+    }
+  }
 
   f32x16 acc[2][TM][TN];  // [0] ah*bh, [1] the 2^-11 terms ah*bl + al*bh
 #pragma unroll
@@ -289,6 +303,30 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   // 2-byte ones.
   float* const Ot = reinterpret_cast<float*>(smem) + wave * OW;  // group 0's staged wave tile
   float* const Og = Ot + kg * (NWG * OW);                        // this group's
+  // Folded LayerNorm (ln_part != NULL): A holds the raw rows x, B the weights scaled by
+  // gamma; with s_j = sum_k B[j][k] the Linear of LN(x) is rstd_i (acc_ij - mean_i s_j) + b'_j.
+  // mean / rstd of this block's rows come from the producer's per-32-column partial
+  // (sum, sum of squares), summed here in a fixed order.
+  float2* const rowstat = reinterpret_cast<float2*>(smem + SMEM_B);
+  if (ln_in) {
+    if ((int)threadIdx.x < BM) {
+      const float inv_c = 1.0f / (float)p.K;
+      const float mean = ln_su * inv_c;
+      const float var = fmaxf(ln_sq * inv_c - mean * mean, 0.f);
+      rowstat[threadIdx.x] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+    }
+    __syncthreads();
+  }
+  // value of accumulator register r of MFMA tile (ti, tj) as it is staged: both K-split
+  // partial accumulators, the folded-LayerNorm correction (group 0 only), the bias
+  auto fin = [&](int ti, int tj, int r, float bv, float sj) {
+    float v = fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]);
+    if (ln_in) {
+      const float2 ms = rowstat[wm0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+      v = ms.y * (v - (kg == 0 ? ms.x * sj : 0.f));
+    }
+    return v + bv;
+  };
   if (p.Vt != nullptr && n0 >= p.vt_col0) {
     // Value heads of the q|k|v projection -> transposed planes Vt[B][H][2][hd][T].  The wave
     // tile is staged TRANSPOSED ([column][row]: a lane's 4 consecutive accumulator registers
@@ -302,12 +340,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       for (int tj = 0; tj < TN; ++tj) {
         const int col = n0 + wn0 + tj * 32 + l31;
         const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
+        const float sj = (ln_in && col < p.N) ? p.ln_colsum[col] : 0.f;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           f32x4 w4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            w4[e] = fmaf(acc[1][ti][tj][4 * g4 + e], T2H_SPLIT_LO_INV, acc[0][ti][tj][4 * g4 + e]) + bv;
+          for (int e = 0; e < 4; ++e) w4[e] = fin(ti, tj, 4 * g4 + e, bv, sj);
           *reinterpret_cast<f32x4*>(Og + (tj * 32 + l31) * OT_LD + ti * 32 + 8 * g4 + 4 * hh) = w4;
         }
       }
@@ -355,10 +393,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     for (int tj = 0; tj < TN; ++tj) {
       const int col = n0 + wn0 + tj * 32 + l31;
       const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
+      const float sj = (ln_in && col < p.N) ? p.ln_colsum[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] =
-            fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]) + bv;
+        Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = fin(ti, tj, r, bv, sj);
     }
   __syncthreads();
   constexpr int CPR = WN / 8;              // 8-column chunks per staged row
@@ -369,7 +407,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     const int c = lane + 64 * (it + kg * NCH);
     const int rl = c / CPR, c8 = (c - rl * CPR) * 8;
     const int row = m0 + wm0 + rl, col = n0 + wn0 + c8;
-    if (row >= p.M || col >= p.N) continue;
+    const bool valid = row < p.M && col < p.N;
+    if (!valid && !p.ln_part_out) continue;
     f32x4 va = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8);
     f32x4 vb = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8 + 4);
     if (KS == 2) {
@@ -386,9 +425,29 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
         vb[e] = fmaxf(vb[e], 0.f);
       }
     }
-    if (p.residual) {
+    if (p.residual && valid) {
       va += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
       vb += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col + 4);
+    }
+    if (p.ln_part_out) {
+      // per-row (sum, sum of squares) of this wave tile's 32 columns for the consumer's
+      // folded LayerNorm: the CPR lanes that hold a row are adjacent
+      float su = 0.f, sq = 0.f;
+      if (valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          su += va[e] + vb[e];
+          sq = fmaf(va[e], va[e], fmaf(vb[e], vb[e], sq));
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < CPR; o <<= 1) {
+        su += __shfl_xor(su, o, 64);
+        sq += __shfl_xor(sq, o, 64);
+      }
+      if (valid && c8 == 0)
+        reinterpret_cast<float2*>(p.ln_part_out)[(int64_t)row * (p.N / WN) + (n0 + wn0) / WN] = make_float2(su, sq);
+      if (!valid) continue;
     }
     if (p.C) {
       *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = va;
@@ -412,6 +471,8 @@ __global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1>
 int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE(a.K % (32 * KS) == 0, "t2h_gemm_split_f32: this tile config needs K %% %d == 0", 32 * KS);
+  T2H_REQUIRE(!a.ln_part_out || BN / WARPS_N == 32,
+              "t2h_gemm_split_f32: LayerNorm partials need a tile config with 32-column wave tiles");
   if (a.Vt)
     T2H_REQUIRE(a.vt_col0 % BN == 0, "t2h_gemm_split_f32: vt_col0=%d must be a multiple of the %d-column tile",
                 a.vt_col0, BN);
@@ -443,6 +504,10 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
                   (!a.residual || (a.ldr % 4 == 0 && t2h_aligned16(a.residual))),
               "t2h_gemm_split_f32: N must be a multiple of 8, ldc / ldr of 4, C / residual 16-byte aligned");
   if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
+  if (a.ln_part)
+    T2H_REQUIRE(a.ln_colsum && a.ln_parts > 0 && a.ln_eps > 0.f, "t2h_gemm_split_f32: incomplete folded-LayerNorm input");
+  if (a.ln_part_out)
+    T2H_REQUIRE(a.N % 32 == 0 && a.Vt == nullptr, "t2h_gemm_split_f32: LayerNorm partials need N %% 32 == 0, no Vt");
   if (a.Vt)
     T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 128 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&
                     a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,

@@ -129,9 +129,20 @@ class SamplerNet:
     tail kernel.  24 x [LN, QKV GEMM, flash MHA, proj GEMM(+res), LN, fc1
     GEMM(+GELU), fc2 GEMM(+res)]."""
 
-    def __init__(self, P, desc, n_head, name='tf', fuse_ln=False, split=False, split_mha=True, n_streams=1):
+    def __init__(self, P, desc, n_head, name='tf', fuse_ln=False, split=False, split_mha=True, n_streams=1,
+                 fold_ln=False):
         self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
         self.split = split
+        # fold_ln (with split + split_mha; parity-tested, but MEASURED 4.8 % SLOWER at B=8 on
+        # MI355X -- 1031 vs 984 ms per batch on the same box: the extra split-row write and
+        # statistics in the producers' epilogues and the per-row correction in the consumers'
+        # cost more than the two 6 us LayerNorm launches per layer save -- so it is off by
+        # default): no LayerNorm launches after the first one.  The
+        # residual GEMMs (proj, fc2) also emit the new x as split rows plus per-row partial
+        # (sum, sum of squares); the next Linear (qkv, fc1) multiplies the RAW rows by the
+        # gamma-scaled weights and applies mean / rstd in its epilogue
+        # (t2h_gemm_split_args.ln_part).
+        self.fold_ln = fold_ln
         # n_streams > 1 (split path): the batch is cut into that many independent slices
         # whose 24-layer kernel chains run on separate HIP streams, so one slice's launch
         # latency / first-tile fill / epilogue tail overlaps the other's main loops
@@ -157,6 +168,8 @@ class SamplerNet:
                                    h_split=ops.split_rows_empty(M, C, dev), y_split=ops.split_rows_empty(M, C, dev),
                                    u_split=ops.split_rows_empty(M, 4 * C, dev),
                                    qk_split=ops.split_rows_empty(M, 3 * C, dev),
+                                   x_split=ops.split_rows_empty(M, C, dev),
+                                   ln_part=torch.empty((M, C // 32, 2), device=dev, dtype=torch.float32),
                                    vt=ops.vt_empty(M // 512 if M % 512 == 0 else 1, self.n_head, 512, dev))}
         return self._buf[key]
 
@@ -184,7 +197,33 @@ class SamplerNet:
             Bs = B // ns
             sl = [(j * Bs * T, (j + 1) * Bs * T, j * Bs, (j + 1) * Bs) for j in range(ns)]
 
+            fold = self.fold_ln and self.split_mha
+            xsp, lnp = buf['x_split'], buf['ln_part']
+
+            def layer_folded(i, lo, hi, b0, b1):
+                p = f'{nm}.{i}'
+                m, xs = hi - lo, x[lo:hi]
+                hd = C // self.n_head
+                if i == 0:  # x comes from the embedding kernel: one real LayerNorm
+                    ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])
+                    ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out_split=qks[lo:hi],
+                                   bias=P[f'{p}.qkv.b'], vt=vt[b0:b1], vt_col0=2 * C, vt_T=T, vt_hd=hd)
+                else:
+                    ops.gemm_split(xsp[lo:hi], P[f'{p}.qkv.w_ln_split'], m, 3 * C, C, out_split=qks[lo:hi],
+                                   bias=P[f'{p}.qkv.b_ln'], vt=vt[b0:b1], vt_col0=2 * C, vt_T=T, vt_hd=hd,
+                                   ln_part=lnp[lo:hi], ln_colsum=P[f'{p}.qkv.colsum'])
+                ops.mha_split(qks[lo:hi], 3 * C, vt[b0:b1], b1 - b0, T, self.n_head, out_split=ys[lo:hi])
+                ops.gemm_split(ys[lo:hi], P[f'{p}.proj.w_split'], m, C, C, out=xs, out_split=xsp[lo:hi],
+                               bias=P[f'{p}.proj.b'], residual=xs, ln_part_out=lnp[lo:hi])
+                ops.gemm_split(xsp[lo:hi], P[f'{p}.fc1.w_ln_split'], m, 4 * C, C, out_split=us[lo:hi],
+                               bias=P[f'{p}.fc1.b_ln'], act=ACT_GELU, ln_part=lnp[lo:hi],
+                               ln_colsum=P[f'{p}.fc1.colsum'])
+                ops.gemm_split(us[lo:hi], P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xs, out_split=xsp[lo:hi],
+                               bias=P[f'{p}.fc2.b'], residual=xs, ln_part_out=lnp[lo:hi])
+
             def layer(i, lo, hi, b0, b1):
+                if fold:
+                    return layer_folded(i, lo, hi, b0, b1)
                 p = f'{nm}.{i}'
                 m, xs = hi - lo, x[lo:hi]
                 ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])

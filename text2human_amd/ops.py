@@ -245,7 +245,7 @@ def pack_split_rows_host(w):
 
 
 def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE,
-               vt=None, vt_col0=0, vt_T=0, vt_hd=64):
+               vt=None, vt_col0=0, vt_T=0, vt_hd=64, ln_part=None, ln_colsum=None, ln_eps=1e-5, ln_part_out=None):
     """C = act(A @ W^T + bias) + residual on the fp16 matrix cores at fp32-class
     accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
     split-row form `out_split` of the result.  With `vt` the output columns from
@@ -264,6 +264,16 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     g.epi_act = act
     if vt is not None:
         g.Vt, g.vt_col0, g.vt_T, g.vt_hd = vt.data_ptr(), vt_col0, vt_T, vt_hd
+    if ln_part is not None:
+        # folded LayerNorm: a_split = un-normalised rows, w_split = gamma-scaled weights,
+        # bias = b + W beta, ln_colsum = row sums of the scaled weights, ln_part [M, parts, 2]
+        _chk_f32(ln_part, ln_colsum)
+        assert ln_part.is_contiguous() and ln_part.shape[0] == M and ln_part.shape[2] == 2
+        g.ln_part, g.ln_colsum, g.ln_parts, g.ln_eps = ln_part.data_ptr(), ln_colsum.data_ptr(), ln_part.shape[1], ln_eps
+    if ln_part_out is not None:
+        _chk_f32(ln_part_out)
+        assert ln_part_out.is_contiguous() and tuple(ln_part_out.shape) == (M, N // 32, 2)
+        g.ln_part_out = ln_part_out.data_ptr()
     lib = _lib.load()
     if _prof is not None:
         _prof['count'] += 1
