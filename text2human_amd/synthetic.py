@@ -451,3 +451,43 @@ def pose_batch(batch, seed=2021, height=512, width=256, cls_num=POSE_CLS_NUM):
     return dict(densepose=dp, shape_attr=shape_attr, upper_fused_attr=attrs[0],
                 lower_fused_attr=attrs[1], outer_fused_attr=attrs[2],
                 img_name=[f'{i}.png' for i in range(batch)])
+
+
+def write_dataset_tree(root, n=3, seed=7, height=1024, width=512):
+    """A tiny DeepFashion-MultiModal style tree (full-resolution PNGs, the three fused
+    texture annotation files and the shape annotation file) for the dataset / entry-point
+    tests.  Returns the option keys the sampling YAMLs use for it."""
+    from PIL import Image
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    dirs = {k: os.path.join(root, k) for k in ('images', 'segm', 'densepose', 'texture_ann', 'shape_ann')}
+    for d in dirs.values():
+        os.makedirs(d, exist_ok=True)
+    names = [f'MEN-Tees_{i:03d}-id_{seed:04d}_{i}_front.jpg' for i in range(n)]
+    rows = {'upper': [], 'lower': [], 'outer': []}
+    shape_rows = []
+    for i, name in enumerate(names):
+        stem = name[:-4]
+        img = rng.integers(0, 256, (height, width, 3), dtype=np.uint8)
+        Image.fromarray(img).save(os.path.join(dirs['images'], name.replace('.jpg', '.png')))
+        Image.fromarray(img).save(os.path.join(dirs['images'], name), quality=95)
+        cells = rng.integers(0, 24, (height // 32, width // 32), dtype=np.uint8)
+        segm = np.kron(cells, np.ones((32, 32), dtype=np.uint8))
+        Image.fromarray(segm).save(os.path.join(dirs['segm'], f'{stem}_segm.png'))
+        dp = np.zeros((height, width, 3), dtype=np.uint8)
+        dp[:, :, 2] = np.kron(rng.integers(0, 25, (height // 16, width // 16), dtype=np.uint8),
+                              np.ones((16, 16), dtype=np.uint8))
+        dp[:, :, :2] = rng.integers(0, 256, (height, width, 2), dtype=np.uint8)
+        Image.fromarray(dp).save(os.path.join(dirs['densepose'], f'{stem}_densepose.png'))
+        for part in rows:
+            rows[part].append(f'{name} {int(rng.integers(0, 18))}')
+        shape_rows.append(name + ' ' + ' '.join(str(int(rng.integers(0, c))) for c in POSE_CLS_NUM))
+    for part, lines in rows.items():
+        with open(os.path.join(dirs['texture_ann'], f'{part}_fused.txt'), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+    shape_path = os.path.join(dirs['shape_ann'], 'test_ann_file.txt')
+    with open(shape_path, 'w') as f:
+        f.write('\n'.join(shape_rows) + '\n')
+    return dict(test_img_dir=dirs['images'], segm_dir=dirs['segm'], pose_dir=dirs['densepose'],
+                test_ann_file=dirs['texture_ann'], texture_ann_file=dirs['texture_ann'],
+                shape_ann_path=shape_path, names=names)
