@@ -232,6 +232,19 @@ typedef struct t2h_sample_heads_args {
 } t2h_sample_heads_args;
 int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream);
 
+/* Sampler training-time forward (models/transformer_model.py:212-274, forward only).
+ * q_sample: mask[b,i] = u[b,i] < t[b] / num_timesteps; x_t = mask ? mask_id : x0.
+ * masked_ce_heads: sum over the 18 heads of F.cross_entropy(logits_h, gt_h, ignore_index=-1,
+ * reduction='none') -- only the head of a token's own texture has a target != -1 -- for the
+ * masked tokens: ce_rows[row] (0 elsewhere) and ce_samples[b] = sum over the T rows of b.
+ * gt_lists: [n_heads][B*T] int64 (-1 = not of that texture), as t2h_vq_argmin_tex_f32 writes. */
+int t2h_q_sample(const int64_t* x0, const float* u, const int64_t* t, int32_t num_timesteps,
+                 int64_t mask_id, int64_t* x_t, uint8_t* mask, int32_t B, int32_t T, void* stream);
+int t2h_masked_ce_heads(const float* hidden, const float* lnf_gamma, const float* lnf_beta,
+                        const float* w_heads, const int64_t* tex, const uint8_t* mask,
+                        const int64_t* gt_lists, float* ce_rows, float* ce_samples, int32_t B, int32_t T,
+                        int32_t C, int32_t n_class, int32_t n_heads, void* stream);
+
 /* ------------------------------------------------------ quantizers ---------
  * VectorQuantizer.forward distance+argmin, vqgan_arch.py:88-92 (first min wins) */
 int t2h_vq_l2_argmin_f32(const float* z, const float* codebook, int64_t* idx,

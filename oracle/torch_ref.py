@@ -286,6 +286,52 @@ def reconstruct(image, texture_mask, sds):
         quant_t=quant_t, top_indices=top_idx, bot_indices=bot_idx)
 
 
+# ---------------------------------------------------------------- sampler training forward
+# (models/transformer_model.py:186-274, forward only)
+
+
+def q_sample(x_0, x_0_gt_list, t, u, num_timesteps, mask_id):
+    """TransformerTextureAwareModel.q_sample, transformer_model.py:212-231, with the uniform
+    draw `u` (= torch.rand_like(x_t.float())) passed in.  Returns (x_t, gt lists with -1 at
+    unmasked positions, mask)."""
+    mask = u < (t.float().unsqueeze(-1) / num_timesteps)
+    x_t = x_0.clone()
+    x_t[mask] = mask_id
+    out = []
+    for gt in x_0_gt_list:
+        g = gt.clone()
+        g[~mask] = -1
+        out.append(g)
+    return x_t, out, mask
+
+
+def train_loss(x_0, x_0_gt_list, segm_tok, tex_tok, sd, t, u, num_timesteps=256, mask_id=18432,
+               loss_type='reweighted_elbo', n_head=8):
+    """TransformerTextureAwareModel._train_loss, transformer_model.py:233-274 (uniform time
+    sampling: pt = 1 / num_timesteps): returns (loss.mean(), vb_loss.mean()) and the per-sample
+    summed cross entropy."""
+    import math
+    x_t, gt_ignore, mask = q_sample(x_0, x_0_gt_list, t, u, num_timesteps, mask_id)
+    logits = transformer_logits(x_t, segm_tok, tex_tok, sd, n_head=n_head)
+    ce = 0
+    for lg, gt in zip(logits, gt_ignore):
+        ce = ce + F.cross_entropy(lg.permute(0, 2, 1), gt, ignore_index=-1, reduction='none').sum(1)
+    pt = torch.ones_like(t).float() / num_timesteps
+    numel = x_0.shape[1:].numel()
+    vb = ce / t / pt / (math.log(2) * numel)
+    if loss_type == 'elbo':
+        loss = vb
+    elif loss_type == 'mlm':
+        denom = mask.float().sum(1)
+        denom[denom == 0] = 1
+        loss = ce / denom
+    elif loss_type == 'reweighted_elbo':
+        loss = (1 - (t / num_timesteps)) * ce / (math.log(2) * numel)
+    else:
+        raise ValueError(loss_type)
+    return loss.mean(), vb.mean(), ce
+
+
 # ---------------------------------------------------------------- transformer
 
 

@@ -220,3 +220,39 @@ def test_encode_side_matches_reference_modules(ns, opt):
         assert torch.equal(a, b)
     _close(quant_t, ref_quant_t, 1e-5)
     _close(zq_o, zqb, 1e-6)
+
+
+@pytest.mark.parametrize('loss_type', ['reweighted_elbo', 'elbo', 'mlm'])
+def test_sampler_train_loss_matches_reference(ns, sds, loss_type):
+    """q_sample + _train_loss of TransformerTextureAwareModel
+    (transformer_model.py:186-274) called unbound on a stub that carries the reference's
+    own TransformerMultiHead."""
+    import importlib
+    import types
+    TM = importlib.import_module('models.transformer_model').TransformerTextureAwareModel
+    sd = synthetic.fill(synthetic.transformer_schema(18432, 1024, 18, 512, 2, 512, 18), seed=5)
+    T = ns.transformer_arch.TransformerMultiHead(
+        codebook_size=18432, segm_codebook_size=1024, texture_codebook_size=18, bert_n_emb=512,
+        bert_n_layers=2, bert_n_head=8, block_size=512, latent_shape=[32, 16], embd_pdrop=0.,
+        resid_pdrop=0., attn_pdrop=0., num_head=18).eval()
+    T.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(9)
+    b = 3
+    tex = torch.randint(0, 18, (b, 512), generator=g)
+    seg = torch.randint(0, 1024, (b, 512), generator=g)
+    code = torch.randint(0, 1024, (b, 512), generator=g)
+    x_0 = code + 1024 * tex
+    gt_list = [torch.where(tex == h, code, torch.full_like(code, -1)) for h in range(18)]
+    stub = types.SimpleNamespace(num_timesteps=256, mask_id=18432, mask_schedule='random', loss_type=loss_type,
+                                 segm_tokens=seg, texture_tokens=tex, _denoise_fn=T)
+    stub.sample_time = types.MethodType(TM.sample_time, stub)
+    stub.q_sample = types.MethodType(TM.q_sample, stub)
+    with torch.no_grad():
+        torch.manual_seed(77)
+        ref_loss, ref_vb = TM._train_loss(stub, x_0, gt_list)
+        torch.manual_seed(77)  # the same draws in the same order: randint (time), rand_like (mask)
+        t = torch.randint(1, 257, (b, )).long()
+        u = torch.rand_like(x_0.float())
+        loss, vb, _ = R.train_loss(x_0, gt_list, seg, tex, sd, t, u, loss_type=loss_type)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * max(1.0, abs(ref_loss.item()))
+    assert abs(vb.item() - ref_vb.item()) <= 1e-5 * max(1.0, abs(ref_vb.item()))

@@ -199,6 +199,112 @@ __global__ __launch_bounds__(SH_THREADS) void sample_head_kernel(
   sample_row<C>(lds, row, hidden, g, bta, w, expo, head, inv_temp, x_t, out_idx, n_class);
 }
 
+// ---- sampler training-time forward (models/transformer_model.py:212-274, forward only)
+// q_sample: mask = u < t/T (fp32 division, like t.float() / num_timesteps); x_t = mask ? mask_id : x_0
+__global__ void q_sample_kernel(const int64_t* __restrict__ x0, const float* __restrict__ u,
+                                const int64_t* __restrict__ t, float num_timesteps, int64_t mask_id,
+                                int64_t* __restrict__ x_t, uint8_t* __restrict__ mask, int T, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool m = u[i] < (float)t[i / T] / num_timesteps;
+  mask[i] = m ? 1 : 0;
+  x_t[i] = m ? mask_id : x0[i];
+}
+
+// Cross entropy of the masked tokens.  F.cross_entropy(..., ignore_index=-1) summed over the
+// 18 heads only ever sees the head of the token's own texture (every other head's target is
+// -1), so: one workgroup per token, rows that are unmasked or have target -1 contribute 0,
+// the others LN_f -> head of their texture -> logsumexp(logits) - logits[target].
+template <int C>
+__global__ __launch_bounds__(SH_THREADS) void masked_ce_kernel(
+    const float* __restrict__ hidden, const float* __restrict__ g, const float* __restrict__ bta,
+    const float* __restrict__ w_heads, const int64_t* __restrict__ tex, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ gt_lists, float* __restrict__ ce, int n, int n_class, int n_heads) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = (int)tex[row];
+  const int64_t target = (head >= 0 && head < n_heads) ? gt_lists[(int64_t)head * n + row] : -1;
+  if (!mask[row] || target < 0) {
+    if (tid == 0) ce[row] = 0.f;
+    return;
+  }
+  constexpr int VPL = C / 256;
+  const float* xr = hidden + (int64_t)row * C;
+  f32x4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      q = fmaf(d, d, q);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i * 256 + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + i * 256 + lane * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+  }
+  constexpr int NW = SH_THREADS / 64;
+  const float* w = w_heads + (int64_t)head * n_class * C;
+  for (int j = wave; j < n_class; j += NW) {
+    const float* wr = w + (int64_t)j * C;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + i * 256 + lane * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a = fmaf(ww[e], v[i][e], a);
+    }
+    a = wave_sum(a);
+    if (lane == 0) lds[j] = a;
+  }
+  __syncthreads();
+  float* red = lds + n_class;
+  float mx = -INFINITY;
+  for (int j = tid; j < n_class; j += SH_THREADS) mx = fmaxf(mx, lds[j]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) mx = fmaxf(mx, red[k]);
+  float se = 0.f;
+  for (int j = tid; j < n_class; j += SH_THREADS) se += expf(lds[j] - mx);
+  se = wave_sum(se);
+  __syncthreads();
+  if (lane == 0) red[wave] = se;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < NW; ++k) tot += red[k];
+    ce[row] = (mx + logf(tot)) - lds[target];
+  }
+}
+
+// out[b] = sum_t x[b][t] in a fixed order (one workgroup per segment)
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int T) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int i = tid; i < T; i += 256) s += x[(int64_t)b * T + i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) out[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // All heads in one launch: one workgroup per CHANGED token (compact list from
 // unmask_step), which picks the head / noise tensor of its own texture.
 template <int C>
@@ -287,5 +393,33 @@ extern "C" int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream)
   hipLaunchKernelGGL(sample_heads_kernel<512>, dim3(a.n_rows), dim3(SH_THREADS), lds,
                      static_cast<hipStream_t>(stream), a);
   T2H_CHECK_LAUNCH("t2h_sample_heads");
+  return T2H_OK;
+}
+
+extern "C" int t2h_q_sample(const int64_t* x0, const float* u, const int64_t* t, int32_t num_timesteps,
+                            int64_t mask_id, int64_t* x_t, uint8_t* mask, int32_t B, int32_t T, void* stream) {
+  T2H_REQUIRE(x0 && u && t && x_t && mask, "t2h_q_sample: NULL pointer");
+  T2H_REQUIRE(B > 0 && T > 0 && num_timesteps > 0, "t2h_q_sample: bad arguments");
+  const int n = B * T;
+  hipLaunchKernelGGL(q_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x0, u,
+                     t, (float)num_timesteps, mask_id, x_t, mask, T, n);
+  T2H_CHECK_LAUNCH("t2h_q_sample");
+  return T2H_OK;
+}
+
+extern "C" int t2h_masked_ce_heads(const float* hidden, const float* lnf_gamma, const float* lnf_beta,
+                                   const float* w_heads, const int64_t* tex, const uint8_t* mask,
+                                   const int64_t* gt_lists, float* ce_rows, float* ce_samples, int32_t B, int32_t T,
+                                   int32_t C, int32_t n_class, int32_t n_heads, void* stream) {
+  T2H_REQUIRE(hidden && lnf_gamma && lnf_beta && w_heads && tex && mask && gt_lists && ce_rows && ce_samples,
+              "t2h_masked_ce_heads: NULL pointer");
+  T2H_REQUIRE(B > 0 && T > 0 && n_class > 0 && n_heads > 0, "t2h_masked_ce_heads: bad arguments");
+  T2H_REQUIRE(C == 512, "t2h_masked_ce_heads: C=%d unsupported (512)", C);
+  const size_t lds = (size_t)(n_class + 2 * (SH_THREADS / 64)) * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(masked_ce_kernel<512>, dim3(B * T), dim3(SH_THREADS), lds, s, hidden, lnf_gamma, lnf_beta,
+                     w_heads, tex, mask, gt_lists, ce_rows, B * T, n_class, n_heads);
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(B), dim3(256), 0, s, ce_rows, ce_samples, T);
+  T2H_CHECK_LAUNCH("t2h_masked_ce_heads");
   return T2H_OK;
 }

@@ -4,6 +4,7 @@ inference subset of the hierarchy (encode side) model."""
 import logging
 
 from .hierarchy_model import VQGANTextureAwareSpatialHierarchyInferenceModel
+from .transformer_model import TransformerTextureAwareModel
 from .sample_model import (BaseSampleModel, SampleFromParsingModel,  # noqa: F401
                            SampleFromPoseModel)
 
@@ -11,6 +12,7 @@ _MODELS = {
     'SampleFromParsingModel': SampleFromParsingModel,
     'SampleFromPoseModel': SampleFromPoseModel,
     'VQGANTextureAwareSpatialHierarchyInferenceModel': VQGANTextureAwareSpatialHierarchyInferenceModel,
+    'TransformerTextureAwareModel': TransformerTextureAwareModel,
 }
 
 

@@ -429,6 +429,33 @@ def sample_head(hidden, lnf_g, lnf_b, w_head, expo, changes, tex, head, temp, x_
                                       _p(out_idx), n, C, n_class, _stream()), 't2h_sample_head')
 
 
+def q_sample(x0, u, t, num_timesteps, mask_id):
+    """x0 int64 [B, T], u f32 [B, T] uniform draw, t int64 [B] -> (x_t int64 [B, T], mask uint8 [B, T])."""
+    _chk_i64(x0, t)
+    _chk_f32(u)
+    B, T = x0.shape
+    x_t = torch.empty_like(x0)
+    mask = torch.empty((B, T), dtype=torch.uint8, device=x0.device)
+    check(_lib.load().t2h_q_sample(_p(x0.contiguous()), _p(u.contiguous()), _p(t.contiguous()), int(num_timesteps),
+                                   int(mask_id), _p(x_t), _p(mask), B, T, _stream()), 't2h_q_sample')
+    return x_t, mask
+
+
+def masked_ce_heads(hidden, lnf_g, lnf_b, w_heads, tex, mask, gt_lists, B, T):
+    """-> (ce_rows f32 [B*T], ce_samples f32 [B]): summed 18-head cross entropy of the masked tokens."""
+    _chk_f32(hidden, lnf_g, lnf_b, w_heads)
+    _chk_i64(tex, gt_lists)
+    n, C = hidden.shape
+    n_heads, n_class = w_heads.shape[0], w_heads.shape[1]
+    assert n == B * T and gt_lists.shape == (n_heads, n) and gt_lists.is_contiguous() and w_heads.is_contiguous()
+    ce_rows = torch.empty(n, dtype=torch.float32, device=hidden.device)
+    ce_samples = torch.empty(B, dtype=torch.float32, device=hidden.device)
+    check(_lib.load().t2h_masked_ce_heads(_p(hidden), _p(lnf_g), _p(lnf_b), _p(w_heads), _p(tex), _p(mask),
+                                          _p(gt_lists), _p(ce_rows), _p(ce_samples), B, T, C, n_class, n_heads,
+                                          _stream()), 't2h_masked_ce_heads')
+    return ce_rows, ce_samples
+
+
 def vq_l2_argmin(z, codebook):
     _chk_f32(z, codebook)
     assert z.is_contiguous() and codebook.is_contiguous()
