@@ -257,8 +257,8 @@ __device__ long long* g_mha_timing = nullptr;  // debug builds only (tools/mha_s
 // Barrier among the 4 waves of ONE key half (monotonic LDS counter).  The two key halves
 // share nothing until the final merge; a block-wide barrier per K/V tile would keep the
 // two waves of a SIMD (same queries, different key half) in lockstep -- both in their
-// matrix phase, then both in their softmax phase -- whereas independent halves, started
-// half a tile apart, run one wave's exp / split VALU work under the other's MFMAs.
+// matrix phase, then both in their softmax phase -- whereas independent halves drift
+// apart and run one wave's exp / split VALU work under the other's MFMAs.
 __device__ __forceinline__ void half_barrier(int* ctr, int target, int lane) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads / writes are done
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -358,7 +358,6 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   // staging threads [0,256) are waves 0-3 = key half 0, [256,512) waves 4-7 = half 1, so a
   // half stages exactly the tiles its own waves read (s_half == kh)
   int bar_n = 0;
-  if (kh == 1) __builtin_amdgcn_s_sleep(24);  // ~1.5k cycles: start the halves out of phase
   const long long tm1 = TM_NOW();
   for (int it = 0; it < nit; ++it) {
     const long long ta = TM_NOW();

@@ -211,14 +211,16 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 
   using set0 = std::integral_constant<int, 0>;
   using set1 = std::integral_constant<int, 1>;
+  // prologue: tiles 0 and 1 are requested back to back (one memory round trip, not two);
+  // tile 0 is complete once at most the L younger loads of tile 1 are outstanding
   issue(set0{}, 0);
+  issue(set1{}, 1);
 #pragma unroll
   for (int i = 0; i < L; ++i) {
-    wait_vmcnt16<0>(rg[0][i]);
+    wait_vmcnt16<L>(rg[0][i]);
     put(i, rg[0][i], 0);
   }
   __builtin_amdgcn_sched_barrier(0);
-  issue(set1{}, 1);
   issue(set0{}, 2);
   __syncthreads();
 
