@@ -628,7 +628,12 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     // is 5-8 % faster; 128x128 only pays once it still fills 2 x 256 CUs
     const int64_t tiles64 = (int64_t)((a.M + 127) / 128) * ((a.N + 63) / 64);
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    cfg = a.M <= 64 ? 2 : (tiles128 >= 1024 ? 1 : ((tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) ? 6 : 0));
+    const int64_t tiles256 = (int64_t)((a.M + 127) / 128) * ((a.N + 255) / 256);
+    if (a.M <= 64) cfg = 2;
+    else if (tiles128 >= 1024) cfg = 1;
+    else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
+    else if (a.N % 256 == 0 && tiles256 % 256 == 0 && !a.Vt && !a.ln_part_out) cfg = 5;  // fc1: one 128x256 tile per CU, -4 %
+    else cfg = 0;
   }
   switch (cfg) {
     case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64
