@@ -632,13 +632,15 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     if (a.M <= 64) cfg = 2;
     else if (tiles128 >= 1024) cfg = 1;
     else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
-    else if (a.N % 256 == 0 && tiles256 % 256 == 0 && !a.Vt && !a.ln_part_out) cfg = 5;  // fc1: one 128x256 tile per CU, -4 %
+    else if (a.N % 128 == 0 && a.M % 256 == 0 && tiles128 / 2 >= 192 && tiles128 / 2 <= 256 && !a.ln_part_out)
+      cfg = 4;  // qkv / fc1 at M = 4096: 192 / 256 tiles of 256x128, at most one per CU
     else cfg = 0;
   }
   switch (cfg) {
     case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64
     case 2: return launch_split<64, 64, 2, 2>(a, s);    // 4 waves, wave tile 32x32
     case 3: return launch_split<128, 64, 4, 2>(a, s);   // 8 waves, wave tile 32x32
+    case 4: return launch_split<256, 128, 4, 2>(a, s);  // 8 waves, wave tile 64x64
     case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
     case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
     case 7: return launch_split<128, 64, 2, 2, 1, true>(a, s);  // cfg 0 with the LDS-DMA main loop
