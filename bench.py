@@ -12,9 +12,11 @@ torch.distributed.run; images are independent so the batch is sharded across
 ranks with no data-path collective (weak scaling, per-rank batch fixed).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  roofline     -- dominant kernel (fp32-MFMA GEMM) algorithmic FLOP/s measured
-                  live with HIP events on the launch stream, vs the 157.3
-                  TFLOP/s dense fp32 matrix peak of gfx950;
+  roofline     -- dominant kernel (the split-precision GEMM of the sampler Linears:
+                  three fp16 partial products per fp32 multiply) algorithmic FLOP/s
+                  measured live with HIP events on the launch stream, vs the 2.5
+                  PFLOP/s dense 16-bit matrix peak of gfx950 (its fp32-equivalent
+                  rate and the 157.3 TFLOP/s fp32 matrix peak are reported beside it);
   cpu_baseline -- the oracle (CPU port of the reference path) timed on this
                   box's host cores on a bounded sample.
 """
@@ -31,7 +33,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense (NOT the 2:1-sparse figure)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16 / bf16 MFMA dense (NOT the 2:1-sparse figure)
 
 
 def parse_args():

@@ -62,7 +62,7 @@ class BaseSampleModel():
         self.ipd = weights.pack_multihead_fcn(P, sds['index_decoder'], 'ipd')
         d_tf = weights.pack_transformer(P, sds['sampler'], 'tf')
         # T2H_SPLIT_GEMM=0 selects the exact-fp32 MFMA GEMMs for the sampler's Linears;
-        # default: split-precision (3 x bf16 planes, six products) on the bf16 matrix
+        # default: split-precision (2 x fp16 planes, three products) on the fp16 matrix
         # cores -- same fp32-class accuracy (tests/test_gpu_split.py), higher throughput
         # (T2H_SPLIT_MHA=0 keeps the attention on the exact-fp32 kernel)
         split = os.environ.get('T2H_SPLIT_GEMM', '1') != '0'
