@@ -9,7 +9,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle.make_golden import golden_inputs  # noqa: E402  (inputs only)
 from text2human_amd import defaults, options, synthetic  # noqa: E402
 from text2human_amd.models import VQGANTextureAwareSpatialHierarchyInferenceModel as M  # noqa: E402
 
@@ -17,7 +16,10 @@ opt = options.dict_to_nonedict(defaults.sample_from_parsing())
 sds = synthetic.make_state_dicts(opt, seed=1234, encode=True)
 model = M(opt, state_dicts=sds)
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'encode_b1.npz'))
-gi = golden_inputs('encode')
+# the seeded inputs of oracle/make_golden.py golden_inputs('encode') (tools must not import oracle/)
+gen0 = torch.Generator().manual_seed(103)
+gi = dict(image=torch.rand(1, 3, 512, 256, generator=gen0) * 2 - 1,
+          texture_mask=synthetic.parsing_batch(1, seed=2021)['texture_mask'])
 model.feed_data(dict(image=gi['image'], texture_mask=gi['texture_mask']))
 top = torch.stack([t.view(1, 32, 16) for t in model.top_indices_list]).cpu().numpy()
 bot = torch.stack(model.gt_indices_list).cpu().numpy()
