@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument('--cpu-sampler-steps', type=int, default=8)
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-baseline-worker', action='store_true')
+    ap.add_argument('--no-exact-fp32', action='store_true',
+                    help='skip the extra step on the exact-fp32 (v_mfma_f32_32x32x2_f32) sampler kernels')
     ap.add_argument('--eager-gpu-baseline', action='store_true',
                     help='also time the oracle sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
     return ap.parse_args()
@@ -280,6 +282,22 @@ def main():
     out['path_tflops'] = 26.17 * out['value'] / world
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.sample_steps, args.cpu_sampler_steps)
+    if world == 1 and not args.no_exact_fp32:
+        # the same step with the sampler's Linears / attention on the exact-fp32 matrix
+        # instructions instead of the split-precision kernels (T2H_SPLIT_GEMM=0), for reference
+        from text2human_amd import engine
+        fast = model.sampler_fn
+        model.sampler_fn = engine.SamplerNet(model.P, model._tf_desc, opt['bert_n_head'], 'tf', split=False)
+        one_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        model.sampler_fn = fast
+        out['exact_fp32_path'] = {'value': args.batch / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt,
+                                  'note': 'sampler Linears and attention on v_mfma_f32_32x32x2_f32 (bitwise fp32 '
+                                          'fma chains); 1 warm-up + 1 timed step'}
     if world == 1 and args.eager_gpu_baseline:
         out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, 16, dev)
     print(json.dumps(out), flush=True)

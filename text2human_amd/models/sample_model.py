@@ -61,6 +61,7 @@ class BaseSampleModel():
         self.index_pred_guidance_encoder = engine.UNetStack(P, 'ipu', d_unet)
         self.ipd = weights.pack_multihead_fcn(P, sds['index_decoder'], 'ipd')
         d_tf = weights.pack_transformer(P, sds['sampler'], 'tf')
+        self._tf_desc = d_tf
         # T2H_SPLIT_GEMM=0 selects the exact-fp32 MFMA GEMMs for the sampler's Linears;
         # default: split-precision (2 x fp16 planes, three products) on the fp16 matrix
         # cores -- same fp32-class accuracy (tests/test_gpu_split.py), higher throughput
