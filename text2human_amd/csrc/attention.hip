@@ -370,6 +370,9 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
     const long long tb = TM_NOW();
     tm_stage += tb - ta;
 
+#ifdef T2H_MHA_IGLP
+    __builtin_amdgcn_iglp_opt(T2H_MHA_IGLP);  // experiment: LLVM's MFMA / exp interleaving strategies
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {  // two 32-key sub-tiles
       // ---- S^T = K Q^T

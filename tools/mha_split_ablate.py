@@ -13,9 +13,11 @@ VARIANTS = (('full', []), ('full+timing', ['-DT2H_MHA_TIMING']), ('noexp', ['-DT
             ('noexp+nosplit', ['-DT2H_MDBG_NOEXP', '-DT2H_MDBG_NOSPLIT']), ('nomma', ['-DT2H_MDBG_NOMMA']),
             ('nostage', ['-DT2H_MDBG_NOSTAGE']),
             ('mma only', ['-DT2H_MDBG_NOEXP', '-DT2H_MDBG_NOSPLIT', '-DT2H_MDBG_NOSTAGE']))
+if len(sys.argv) > 1 and sys.argv[1] == 'iglp':  # LLVM scheduling strategies (__builtin_amdgcn_iglp_opt)
+    VARIANTS = (('full', []), ) + tuple((f'iglp_opt({v})', [f'-DT2H_MHA_IGLP={v}']) for v in (0, 1, 2, 3)) + (('full again', []), )
 B, T, H, C = 8, 512, 8, 512
 for tag, extra in VARIANTS:
-    so = f'/tmp/libt2h_mab_{tag.replace("+", "_").replace(" ", "_")}.so'
+    so = '/tmp/libt2h_mab_' + ''.join(ch if ch.isalnum() else '_' for ch in tag) + '.so'
     subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-comment',
                     f'-I{ROOT}/include', *extra, os.path.join(csrc, 'api.hip'), os.path.join(csrc, 'attention.hip'),
                     '-o', so], check=True)
