@@ -425,12 +425,24 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   }
   // value of accumulator register r of MFMA tile (ti, tj) as it is staged: both K-split
   // partial accumulators, the folded-LayerNorm correction (group 0 only), the bias
+  // (the 16 rows of a lane's registers in MFMA row-tile ti are 4 runs of 4 consecutive
+  // rows: their (mean, rstd) are fetched as 8 16-byte LDS reads per ti, not 16 x TN small ones)
+  float2 rs[16];
+  auto load_rowstats = [&](int ti) {
+    if (!ln_in) return;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4* q = reinterpret_cast<const f32x4*>(rowstat + wm0 + ti * 32 + 8 * g4 + 4 * hh);
+      const f32x4 lo = q[0], hi2 = q[1];
+      rs[4 * g4 + 0] = make_float2(lo[0], lo[1]);
+      rs[4 * g4 + 1] = make_float2(lo[2], lo[3]);
+      rs[4 * g4 + 2] = make_float2(hi2[0], hi2[1]);
+      rs[4 * g4 + 3] = make_float2(hi2[2], hi2[3]);
+    }
+  };
   auto fin = [&](int ti, int tj, int r, float bv, float sj) {
     float v = fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]);
-    if (ln_in) {
-      const float2 ms = rowstat[wm0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
-      v = ms.y * (v - (kg == 0 ? ms.x * sj : 0.f));
-    }
+    if (ln_in) v = rs[r].y * (v - (kg == 0 ? rs[r].x * sj : 0.f));
     return v + bv;
   };
   if (p.Vt != nullptr && n0 >= p.vt_col0) {
@@ -441,7 +453,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     // in one k16-step: they sit at the 8 consecutive positions 16j + 8h .. + 7 of the plane,
     // so the store is one 16-byte piece per plane and contiguous across lanes.
 #pragma unroll
-    for (int ti = 0; ti < TM; ++ti)
+    for (int ti = 0; ti < TM; ++ti) {
+      load_rowstats(ti);
 #pragma unroll
       for (int tj = 0; tj < TN; ++tj) {
         const int col = n0 + wn0 + tj * 32 + l31;
@@ -455,6 +468,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
           *reinterpret_cast<f32x4*>(Og + (tj * 32 + l31) * OT_LD + ti * 32 + 8 * g4 + 4 * hh) = w4;
         }
       }
+    }
     __syncthreads();
     constexpr int RG = WM / 8;                   // 8-key chunks per staged column
     constexpr int NCV = RG * WN / 64 / KS;       // chunks per lane
@@ -494,7 +508,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     return;
   }
 #pragma unroll
-  for (int ti = 0; ti < TM; ++ti)
+  for (int ti = 0; ti < TM; ++ti) {
+    load_rowstats(ti);
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) {
       const int col = n0 + wn0 + tj * 32 + l31;
@@ -504,6 +519,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       for (int r = 0; r < 16; ++r)
         Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = fin(ti, tj, r, bv, sj);
     }
+  }
   __syncthreads();
   constexpr int CPR = WN / 8;              // 8-column chunks per staged row
   constexpr int NCH = WM * CPR / 64 / KS;  // chunks per lane (the K groups share the stores)

@@ -133,11 +133,12 @@ class SamplerNet:
                  fold_ln=False):
         self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
         self.split = split
-        # fold_ln (with split + split_mha; parity-tested, but MEASURED 4.8 % SLOWER at B=8 on
-        # MI355X -- 1031 vs 984 ms per batch on the same box: the extra split-row write and
-        # statistics in the producers' epilogues and the per-row correction in the consumers'
-        # cost more than the two 6 us LayerNorm launches per layer save -- so it is off by
-        # default): no LayerNorm launches after the first one.  The
+        # fold_ln (with split + split_mha; parity-tested, but MEASURED 1 % SLOWER at B=8 on
+        # MI355X -- 1020 vs 1010 ms per batch on the same box: the extra split-row write and
+        # statistics in the producers' epilogues (+2-3 us per launch) and the per-row
+        # correction in the consumers' (+3-4 us, tools/fold_ln_probe.py) cost what the two
+        # 6-7 us LayerNorm launches per layer save -- so it is off by default): no LayerNorm
+        # launches after the first one.  The
         # residual GEMMs (proj, fc2) also emit the new x as split rows plus per-row partial
         # (sum, sum of squares); the next Linear (qkv, fc1) multiplies the RAW rows by the
         # gamma-scaled weights and applies mean / rstd in its epilogue
