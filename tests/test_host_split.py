@@ -44,3 +44,9 @@ def test_value_plane_key_order_is_the_mfma_contraction_order():
                 for e in range(8):
                     key = 32 * grp + 16 * j + 4 * h + (e & 3) + 8 * (e >> 2)
                     assert pos[key].item() == 32 * grp + 16 * j + 8 * h + e
+
+
+def test_out_of_range_weights_are_rejected_loudly():
+    import pytest
+    with pytest.raises(ValueError):
+        ops.pack_split_rows_host(torch.full((32, 32), 7.0e4))

@@ -215,6 +215,9 @@ def split_planes_host(x):
     """(hi, lo) fp16 planes of an fp32 tensor: x = hi + lo / 2048 (round-to-nearest-even,
     bit-identical to the device split)."""
     x = x.float()
+    if x.numel() and float(x.abs().max()) >= 65504.0:
+        raise ValueError('split rows carry fp16 planes: |x| must stay below 65504 '
+                         f'(got {float(x.abs().max()):.3g}); use the exact-fp32 kernels (T2H_SPLIT_GEMM=0)')
     hi = x.half()
     lo = ((x - hi.float()) * SPLIT_LO_SCALE).half()
     return hi, lo
