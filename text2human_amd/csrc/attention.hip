@@ -260,11 +260,18 @@ __device__ long long* g_mha_timing = nullptr;  // debug builds only (tools/mha_s
 // matrix phase, then both in their softmax phase -- whereas independent halves drift
 // apart and run one wave's exp / split VALU work under the other's MFMAs.
 __device__ __forceinline__ void half_barrier(int* ctr, int target, int lane) {
+#ifdef T2H_MHA_BLOCK_BARRIER  // experiment: plain block barrier (tools/mha_split_ablate.py barrier)
+  __syncthreads();
+#else
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads / writes are done
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+#ifndef T2H_MHA_NOSLEEP
     __builtin_amdgcn_s_sleep(1);
+#endif
+  }
   asm volatile("" ::: "memory");
+#endif
 }
 
 __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restrict__ qk, int ld_cols,
