@@ -1,24 +1,31 @@
 #!/usr/bin/env python
 """Benchmark of the Text2Human sampling hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config parsing|pose|hires]
 
-One "step" = one full pass of `sample_from_parsing` over one batch of synthetic
-512x256 parsing maps per GPU (BASELINE.json configs[1]: batch 8 per GPU):
-segm tokenizer -> 256-step texture-aware transformer index sampler -> index
-refinement -> hierarchical VQGAN decode -> uint8 images, all inputs resident in
-HBM before the timed region.  For N > 1 the driver launches this file with
-torch.distributed.run; images are independent so the batch is sharded across
-ranks with no data-path collective (weak scaling, per-rank batch fixed).
+One "step" = one full pass of the hot path over one batch of synthetic inputs per GPU, all
+inputs resident in HBM before the timed region:
+
+  parsing (default; BASELINE.json configs[1], sharded = configs[3]): `sample_from_parsing`,
+          batch 8 per GPU: segm tokenizer -> 256-step texture-aware transformer index sampler
+          -> index refinement -> hierarchical VQGAN decode -> uint8 512x256 images;
+  pose    (configs[2]): `sample_from_pose`, batch 32 per GPU: ShapeUNet parsing generator ->
+          tokenizer -> sampler -> refine -> decode;
+  hires   (configs[4]): the 1024x512 upscaled hierarchy (SURVEY.md 8(d) interpretation: sample at
+          32x16, nearest-x2 both quantised latents, fully-convolutional decode), batch 8 per GPU.
+
+For N > 1 the driver launches this file with torch.distributed.run; images are independent so
+the batch is sharded across ranks with no data-path collective (weak scaling, per-rank batch
+fixed); weights are synthesised on rank 0 and broadcast over RCCL.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  roofline     -- dominant kernel (the split-precision GEMM of the sampler Linears:
-                  three fp16 partial products per fp32 multiply) algorithmic FLOP/s
-                  measured live with HIP events on the launch stream, vs the 2.5
-                  PFLOP/s dense 16-bit matrix peak of gfx950 (its fp32-equivalent
-                  rate and the 157.3 TFLOP/s fp32 matrix peak are reported beside it);
-  cpu_baseline -- the oracle (CPU port of the reference path) timed on this
-                  box's host cores on a bounded sample.
+  roofline     -- dominant kernel (the split-precision GEMM of the sampler Linears: three fp16
+                  partial products per fp32 multiply) measured live with HIP events on the
+                  launch stream: `frac` = EXECUTED fp16 matrix FLOP/s over the 2.5 PFLOP/s dense
+                  16-bit peak, `frac_useful` = the reference's fp32 FLOP count over the same peak;
+  stages       -- per-stage times (HIP events) with the decode stage's compute AND HBM fractions;
+  parity       -- the split-precision step against the exact-fp32 step on the same batch / seed;
+  cpu_baseline -- the oracle (CPU port of the reference path) timed on this box's host cores.
 """
 import argparse
 import json
@@ -34,69 +41,99 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16 / bf16 MFMA dense (NOT the 2:1-sparse figure)
+HBM_PEAK_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec
+
+# algorithmic work per image (exact, 2 * MAC) and algorithmic HBM bytes
+GFLOP_IMAGE = dict(sampler_step=99.858, tokenizer=40.49, refine=2.19, decode=562.88, pose=239.86,
+                   decode_hires=2380.0)
+DECODE_BYTES_IMAGE = dict(parsing=1.870e9, hires=7.48e9)
+DECODE_WEIGHT_BYTES = 216.5e6
+WORKLOADS = {
+    'parsing': dict(batch=8, ref='BASELINE.json configs[1] (configs[3] when sharded)',
+                    desc='sample_from_parsing.yml, top+bottom VQGAN decode + index sampler'),
+    'pose': dict(batch=32, ref='BASELINE.json configs[2]',
+                 desc='sample_from_pose.yml (ParsingGen -> hierarchy VQGAN -> sampler end-to-end)'),
+    'hires': dict(batch=8, ref='BASELINE.json configs[4]',
+                  desc='1024x512 upscaled hierarchy (32x16 sampling, nearest-x2 latents, 64x32 / 128x64 '
+                       'token grids through the fully-convolutional decoders)'),
+}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--config', choices=sorted(WORKLOADS), default='parsing')
+    ap.add_argument('--batch', type=int, default=0, help='images per GPU per step (0 = the config default)')
     ap.add_argument('--sample-steps', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sampler-steps', type=int, default=8)
+    ap.add_argument('--cpu-sampler-steps', type=int, default=32)
+    ap.add_argument('--cpu-repeats', type=int, default=3)
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-baseline-worker', action='store_true')
     ap.add_argument('--no-exact-fp32', action='store_true',
-                    help='skip the extra step on the exact-fp32 (v_mfma_f32_32x32x2_f32) sampler kernels')
+                    help='skip the extra steps on the exact-fp32 (v_mfma_f32_32x32x2_f32) sampler kernels')
+    ap.add_argument('--exact-steps', type=int, default=3)
     ap.add_argument('--eager-gpu-baseline', action='store_true',
                     help='also time the oracle sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
-    return ap.parse_args()
+    ap.add_argument('--stub-model', action='store_true',
+                    help='TEST ONLY (tests/test_bench_dist.py): CPU + gloo + a stub model, to exercise the '
+                         'multi-rank shard / seed / timing / gather logic of this file without a GPU')
+    return ap.parse_args(argv)
 
 
-def cpu_baseline_worker(sample_steps, n_sub, threads):
-    """Times the oracle (oracle/torch_ref.py = CPU port of the reference path)
-    on a bounded sample: B=1, tokenizer + n_sub sampler steps (scaled to
-    `sample_steps`) + refine + decode.  Runs in its own process (see below)."""
+# --------------------------------------------------------------------------- CPU baseline
+
+
+def cpu_baseline_worker(sample_steps, n_sub, threads, repeats):
+    """Times the oracle (oracle/torch_ref.py = CPU port of the reference path) on a bounded
+    sample: B=1, tokenizer + n_sub sampler steps (scaled to `sample_steps`) + refine + decode,
+    `repeats` times, median.  Runs in its own process (see below)."""
     from oracle import torch_ref as R
     from text2human_amd import defaults, options, synthetic
     torch.set_num_threads(threads)
     opt = options.dict_to_nonedict(defaults.sample_from_parsing())
     sds = synthetic.make_state_dicts(opt, seed=1234)
     batch = synthetic.parsing_batch(1, seed=2021)
-    torch.manual_seed(2021)
+    runs = []
     with torch.no_grad():
         R.transformer_logits(torch.zeros(1, 512, dtype=torch.long), torch.zeros(1, 512, dtype=torch.long),
                              torch.zeros(1, 512, dtype=torch.long), sds['sampler'], heads={0})  # warm up
-        t0 = time.perf_counter()
-        tok = R.segm_tokens(batch['segm'], sds['segm_encoder'], sds['segm_quant_conv'],
-                            sds['segm_quantizer']['embedding.weight']).view(1, -1)
-        t1 = time.perf_counter()
-        top = R.sample_fn(tok, batch['texture_mask'], sds['sampler'], sample_steps=n_sub,
-                          noise=R.TorchNoise('cpu'))
-        t2 = time.perf_counter()
-        R.refine_and_decode(top, batch['texture_mask'], sds)
-        t3 = time.perf_counter()
-    per_image = (t1 - t0) + (t2 - t1) * (sample_steps / n_sub) + (t3 - t2)
+        for _ in range(repeats):
+            torch.manual_seed(2021)
+            t0 = time.perf_counter()
+            tok = R.segm_tokens(batch['segm'], sds['segm_encoder'], sds['segm_quant_conv'],
+                                sds['segm_quantizer']['embedding.weight']).view(1, -1)
+            t1 = time.perf_counter()
+            top = R.sample_fn(tok, batch['texture_mask'], sds['sampler'], sample_steps=n_sub,
+                              noise=R.TorchNoise('cpu'))
+            t2 = time.perf_counter()
+            R.refine_and_decode(top, batch['texture_mask'], sds)
+            t3 = time.perf_counter()
+            runs.append(((t1 - t0) + (t2 - t1) * (sample_steps / n_sub) + (t3 - t2), t1 - t0, t2 - t1, t3 - t2))
+    runs.sort()
+    per_image, tk, sm, dc = runs[len(runs) // 2]
     return dict(value=1.0 / per_image, unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample=(f'B=1: tokenizer {t1 - t0:.2f}s + {n_sub} of {sample_steps} sampler steps '
-                        f'{t2 - t1:.2f}s (scaled x{sample_steps / n_sub:g}) + refine/decode {t3 - t2:.2f}s'
-                        f' -> {per_image:.1f} s/image'))
+                sample=(f'median of {repeats}: B=1, tokenizer {tk:.2f}s + {n_sub} of {sample_steps} sampler steps '
+                        f'{sm:.2f}s (scaled x{sample_steps / n_sub:g}) + refine/decode {dc:.2f}s'
+                        f' -> {per_image:.1f} s/image; all runs s/image: '
+                        + ', '.join(f'{r[0]:.1f}' for r in runs)))
 
 
-def cpu_baseline(sample_steps, n_sub):
-    """Runs the worker in a fresh process (no GPU context, own OpenMP pool) with a
-    hard time box so the benchmark always finishes; threads = min(cores, 32):
-    torch's CPU kernels on B=1 shapes stop scaling (and degrade) far below the
-    hundreds of hardware threads of the GPU hosts."""
+def cpu_baseline(sample_steps, n_sub, repeats):
+    """Runs the worker in a fresh process (no GPU context, own OpenMP pool) with a hard time
+    box so the benchmark always finishes; threads = min(cores, 32): torch's CPU kernels on B=1
+    shapes stop scaling (and degrade) far below the hundreds of hardware threads of the hosts."""
     import subprocess
     threads = min(os.cpu_count() or 1, 32)
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--sample-steps',
-           str(sample_steps), '--cpu-sampler-steps', str(n_sub), '--cpu-threads', str(threads)]
+           str(sample_steps), '--cpu-sampler-steps', str(n_sub), '--cpu-threads', str(threads),
+           '--cpu-repeats', str(repeats)]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
                HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         if line:
             return json.loads(line[-1])
@@ -104,17 +141,15 @@ def cpu_baseline(sample_steps, n_sub):
                     sample=f'worker failed: {r.stderr[-300:]}')
     except subprocess.TimeoutExpired:
         return dict(value=None, unit='images/s', cores=threads, kind='port',
-                    sample='worker exceeded its 240 s time box')
+                    sample='worker exceeded its 300 s time box')
 
 
 def eager_gpu_baseline(model, batch, sds, n_sub, dev):
-    """The un-tuned GPU baseline of SURVEY.md 8(d): the oracle's sampler (the
-    reference's algorithm as eager PyTorch-ROCm fp32 ops: rocBLAS/hipBLASLt GEMMs,
-    unfused softmax / LayerNorm / GELU / Categorical tail) on this same GPU and batch,
-    n_sub steps, next to this package's sampler on the same n_sub steps."""
+    """The un-tuned GPU baseline of SURVEY.md 8(d): the oracle's sampler (the reference's
+    algorithm as eager PyTorch-ROCm fp32 ops) on this same GPU and batch."""
     from oracle import torch_ref as R
     sd = {k: v.to(dev) for k, v in sds['sampler'].items()}
-    tok = model.segm_tokens.view(batch['segm'].shape[0], -1)
+    tok = model.segm_tokens.view(model.batch_size, -1)
 
     def timed(fn):
         fn(2)
@@ -125,115 +160,231 @@ def eager_gpu_baseline(model, batch, sds, n_sub, dev):
         return 1000.0 * (time.perf_counter() - t0) / n_sub
 
     with torch.no_grad():
-        eager = timed(lambda n: R.sample_fn(tok, batch['texture_mask'], sd, sample_steps=n, noise=R.TorchNoise(dev)))
+        eager = timed(lambda n: R.sample_fn(tok, model.texture_mask, sd, sample_steps=n, noise=R.TorchNoise(dev)))
     ours = timed(lambda n: model.sample_fn(temp=1, sample_steps=n))
     return dict(kind='oracle sampler as eager PyTorch-ROCm fp32 on the same GPU', sampler_ms_per_step=eager,
                 this_package_sampler_ms_per_step=ours, speedup=eager / ours,
                 sample=f'B={tok.shape[0]}, {n_sub} sampler steps each (the sampler is 97% of the path)')
 
 
+# --------------------------------------------------------------------------- PMC side data
+
+
 def pmc_traffic(kernel_label):
-    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be
-    read from inside the benchmark; they come from the separate rocprofv3 --pmc
-    passes of this same bench command committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE in their own passes, gfx950 FETCH x2 correction, see
-    tools/pmc_summary.py) -- launch-weighted over the kernel's shapes."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
-    m = __import__('re').match(r'gemm_kernel<(\d+)x(\d+)x(\d+)(w8)?,amode=(\d),pro=(\d),btrans=(\d)>', kernel_label)
-    if not os.path.exists(path):
-        return {'traffic': None}
-    if kernel_label.startswith('gemm_split'):
-        rows = [r for r in json.load(open(path)) if r['kernel'].startswith('gemm_split_kernel')]
-    elif m:
-        bm, bn, bk, w8, am, pro, bt = m.groups()
-        wm, wn = ('4', '2') if w8 else (('4', '1') if bn == '32' else ('2', '2'))
-        name = f'gemm_kernel<{bm}, {bn}, {bk}, {wm}, {wn}, {am}, {pro}, {"true" if bt == "1" else "false"}>'
-        rows = [r for r in json.load(open(path)) if r['kernel'] == name]
+    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be read from inside
+    the benchmark; they come from the separate rocprofv3 --pmc passes of this same bench command
+    committed under profiles/ (FETCH_SIZE and WRITE_SIZE in their own passes, gfx950 FETCH x2
+    correction, tools/pmc_summary.py) -- launch-weighted over the kernel's shapes."""
+    for name in ('r02_pmc_summary.json', 'r01_pmc_summary.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            break
     else:
         return {'traffic': None}
+    if not kernel_label.startswith('gemm_split'):
+        return {'traffic': None}
+    rows = [r for r in json.load(open(path)) if r['kernel'].startswith('gemm_split')]
     if not rows:
         return {'traffic': None}
     n = sum(r['launches'] for r in rows)
     mb = sum(r['traffic_mb'] * r['launches'] for r in rows) / n
     util = sum(r['mfma_util'] * r['launches'] for r in rows) / n
     return {'traffic': mb * 1e6, 'traffic_unit': 'bytes/launch', 'mfma_util_pmc': util,
-            'traffic_source': 'profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'}
+            'traffic_source': f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'}
 
 
-def main():
-    args = parse_args()
+# --------------------------------------------------------------------------- distributed glue
+
+
+def init_dist(backend, dev):
+    """RCCL prints a version banner on stdout at communicator creation; stdout is reserved for
+    the ONE JSON line, so fd 1 is routed to stderr while the communicator comes up."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        dist.barrier()
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+    finally:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # the banner goes through C stdio: drain it to stderr now
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    return dist
+
+
+def pin_launch_thread(local_rank, local_world):
+    """One disjoint block of host cores per rank, so eight launch threads (each doing one host
+    read per sampling step) never share or migrate between cores.  T2H_NO_PIN=1 disables."""
+    if os.environ.get('T2H_NO_PIN') == '1' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        k = max(1, len(cpus) // max(1, local_world))
+        mine = cpus[local_rank * k:(local_rank + 1) * k] or cpus
+        os.sched_setaffinity(0, mine)
+        return [mine[0], mine[-1]]
+    except OSError:
+        return None
+
+
+class StubModel:
+    """TEST ONLY: stands in for the model classes on CPU so that the multi-rank logic of this
+    file (shard, per-rank seed, barrier, max-over-ranks, gathers, the JSON line) runs under gloo."""
+
+    def __init__(self, sds):
+        self.w = float(sds['sampler']['w'].sum())
+        self.batch_size = 0
+
+    def feed_data(self, batch):
+        self.segm = batch['segm']
+        self.batch_size = self.segm.shape[0]
+
+    def sample_fn(self, temp=1, sample_steps=None):
+        time.sleep(0.01)
+        r = torch.rand(self.batch_size, 4)  # consumes the (re-seeded) global generator
+        return [(self.segm.reshape(self.batch_size, -1)[:, :4] + r + self.w).double()]
+
+    def decode_indices(self, top, want_u8=True, upscale=False, return_inter=False):
+        u8 = (top[0][:, :3].abs() * 1000).to(torch.int64).remainder(256).to(torch.uint8)
+        return None, u8.view(self.batch_size, 1, 1, 3).expand(self.batch_size, 512, 256, 3).contiguous()
+
+
+# --------------------------------------------------------------------------- main
+
+
+def main(argv=None):
+    args = parse_args(argv)
     if args.cpu_baseline_worker:
         print(json.dumps(cpu_baseline_worker(args.sample_steps, args.cpu_sampler_steps,
-                                             args.cpu_threads or (os.cpu_count() or 1))), flush=True)
+                                             args.cpu_threads or (os.cpu_count() or 1), args.cpu_repeats)),
+              flush=True)
         return
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU path exists)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    use_dist = world > 1 or os.environ.get("T2H_FORCE_DIST") == "1"  # test hook: RCCL init with 1 rank
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # RCCL prints a version banner on stdout at communicator creation; stdout is
-        # reserved for the ONE JSON line, so route fd 1 to stderr while RCCL comes up.
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group('nccl', device_id=dev)
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            # the banner goes through C stdio, which block-buffers when stdout is a pipe and
-            # would otherwise flush it to the restored fd 1 at exit: drain it to stderr now
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    stub = args.stub_model
+    if stub:
+        dev, backend = torch.device('cpu'), 'gloo'
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU path exists)'
+        torch.cuda.set_device(local_rank)
+        dev, backend = torch.device('cuda', local_rank), 'nccl'
+    pinned = pin_launch_thread(local_rank, local_world)
+    use_dist = world > 1 or os.environ.get('T2H_FORCE_DIST') == '1'  # test hook: RCCL init with 1 rank
+    dist = init_dist(backend, dev) if use_dist else None
+    dworld = 2 if use_dist else 1  # "is distributed" switch of the shard helpers
 
-    from text2human_amd import defaults, ops, options, shard, synthetic
-    from text2human_amd.models import SampleFromParsingModel
+    from text2human_amd import shard
+    wl = WORKLOADS[args.config]
+    batch_per_gpu = args.batch or wl['batch']
+    sync = (lambda: None) if stub else torch.cuda.synchronize
 
-    opt = options.dict_to_nonedict(defaults.sample_from_parsing())
-    opt['sample_steps'] = args.sample_steps
-    sds = synthetic.make_state_dicts(opt, seed=1234)
-    model = SampleFromParsingModel(opt, state_dicts=sds)
+    # ---- weights: synthesised ONCE (rank 0) and broadcast, not 8x on the host cores
+    t_w0 = time.perf_counter()
+    if stub:
+        sds = shard.broadcast_state_dicts({'sampler': {'w': torch.arange(6.0).view(2, 3)}} if rank == 0 else None,
+                                          dworld, dev)
+        model = StubModel(sds)
+        set_seed = torch.manual_seed
+        opt = None
+    else:
+        from text2human_amd import defaults, ops, options, synthetic
+        from text2human_amd.models import SampleFromParsingModel, SampleFromPoseModel
+        pose = args.config == 'pose'
+        opt = options.dict_to_nonedict(defaults.sample_from_pose() if pose else defaults.sample_from_parsing())
+        opt['sample_steps'] = args.sample_steps
+        sds = synthetic.make_state_dicts(opt, seed=1234) if rank == 0 else None
+        sds = shard.broadcast_state_dicts(sds, dworld, dev)
+        model = (SampleFromPoseModel if pose else SampleFromParsingModel)(opt, state_dicts=sds)
+        set_seed = options.set_random_seed
+    t_weights = time.perf_counter() - t_w0
 
-    # this rank's shard of the global batch (contiguous split, SURVEY.md 8(e))
-    lo, hi = shard.shard_range(args.batch * world, rank, world)
-    full = synthetic.parsing_batch(args.batch * world, seed=2021)
-    batch = dict(segm=full['segm'][lo:hi].to(dev), texture_mask=full['texture_mask'][lo:hi].to(dev),
-                 img_name=full['img_name'][lo:hi])
+    # ---- this rank's shard of the global batch (contiguous split, SURVEY.md 8(e)); seed 2021 on
+    # every rank's OWN shard (the oracle of a sharded run is the reference on that shard)
+    lo, hi = shard.shard_range(batch_per_gpu * world, rank, world)
+    if stub:
+        g = torch.Generator().manual_seed(2021)
+        full = dict(segm=torch.rand(batch_per_gpu * world, 1, 8, 4, generator=g))
+    elif args.config == 'pose':
+        full = synthetic.pose_batch(batch_per_gpu * world, seed=2021)
+    else:
+        full = synthetic.parsing_batch(batch_per_gpu * world, seed=2021)
+    batch = {k: (v[lo:hi].to(dev) if torch.is_tensor(v) else v[lo:hi]) for k, v in full.items()}
+    upscale = args.config == 'hires'
+    stage_ms = {}
 
-    def one_step():
-        options.set_random_seed(2021)
-        model.feed_data(batch)
-        top = model.sample_fn(temp=1, sample_steps=args.sample_steps)
-        _, u8 = model.decode_indices(top, want_u8=True)
-        return u8
+    def one_step(events=None):
+        """events: list that receives (stage name, start event, end event)."""
+        def mark(name, fn):
+            if events is None or stub:
+                return fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            events.append((name, e0, e1))
+            return r
+
+        set_seed(2021)
+        if args.config == 'pose':
+            def front():
+                model.feed_data(batch)
+                model.generate_parsing_map()
+            mark('pose_front_end', front)
+
+            def tok():
+                model.generate_quantized_segm()
+                model.generate_texture_map()
+            mark('tokenizer', tok)
+        else:
+            mark('tokenizer', lambda: model.feed_data(batch))
+        top = mark('sampler', lambda: model.sample_fn(temp=1, sample_steps=args.sample_steps))
+        _, u8 = mark('refine_decode', lambda: model.decode_indices(top, want_u8=True, upscale=upscale))
+        return top, u8
 
     for _ in range(args.warmup):
         one_step()
-    shard.barrier(2 if use_dist else 1)
-    torch.cuda.synchronize()
-    ops.gemm_profile_start(every=37)  # HIP-event pairs around a sample of GEMM launches
+    shard.barrier(dworld)
+    sync()
+    if not stub:
+        ops.gemm_profile_start(every=37)  # HIP-event pairs around a sample of GEMM launches
+    events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        u8 = one_step()
-    torch.cuda.synchronize()
-    shard.barrier(2 if use_dist else 1)
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, 2 if use_dist else 1, dev)
-    prof = ops.gemm_profile_stop()
-    assert u8.shape == (hi - lo, 512, 256, 3)
+        top, u8 = one_step(events)
+    sync()
+    my_elapsed = time.perf_counter() - t0
+    shard.barrier(dworld)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dworld, dev)
+    prof = {} if stub else ops.gemm_profile_stop()
+    hw = (1024, 512) if upscale else (512, 256)
+    assert tuple(u8.shape) == (hi - lo, hw[0], hw[1], 3), tuple(u8.shape)
+    for name, e0, e1 in events:
+        stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / args.steps
+    per_rank_ms = shard.gather_floats(1000.0 * my_elapsed / args.steps, dworld, dev)
+    # a checksum of every rank's images reaches rank 0 (the optional image gather of SURVEY 8(e))
+    sums = shard.gather_floats(float(u8.to(torch.float64).sum()), dworld, dev)
 
     if rank != 0:
+        if use_dist:
+            dist.destroy_process_group()
         return
-    n_img = args.batch * world * args.steps
+    n_img = batch_per_gpu * world * args.steps
+    split_on = os.environ.get('T2H_SPLIT_GEMM', '1') != '0'
     out = {
-        'metric': '512x256 images/sec (sample_from_parsing)',
+        'metric': ('512x256 images/sec (sample_from_parsing)' if args.config == 'parsing' else
+                   '512x256 images/sec (sample_from_pose)' if args.config == 'pose' else
+                   '1024x512 images/sec (upscaled hierarchy)'),
         'value': n_img / elapsed,
         'unit': 'images/s',
         'n_gpus': world,
@@ -243,34 +394,48 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': ('f32' if os.environ.get('T2H_SPLIT_GEMM', '1') == '0' else
+        'dtype': ('stub' if stub else 'f32' if not split_on else
                   'f32 (sampler Linears + attention as 2xfp16-split MFMA, 3 partial products, fp32 accumulate: '
-                  'fp32-class accuracy, tokens bit-exact vs the fp32 oracle; everything else exact-fp32 MFMA)'),
+                  '22-bit operands, fp32-class accuracy -- see "parity"; everything else exact-fp32 MFMA)'),
         'data': 'synthetic',
         'config': {
-            'workload': (f'sample_from_parsing.yml batch={args.batch}/GPU, {args.sample_steps} sampling '
-                         'steps, top+bottom VQGAN decode + index sampler (BASELINE.json configs[1])'),
-            'global_batch': args.batch * world,
+            'workload': (f'{wl["desc"]}, batch={batch_per_gpu}/GPU, {args.sample_steps} sampling steps '
+                         f'({wl["ref"]})'),
+            'global_batch': batch_per_gpu * world,
             'sample_steps': args.sample_steps,
-            'weights': 'synthetic seed 1234 (reference .pth layout)',
-            'rng': 'torch global generator (reference contract)',
+            'weights': 'synthetic seed 1234 (reference .pth layout), built on rank 0 and broadcast',
+            'rng': 'torch global generator (reference contract), seed 2021 per rank shard',
             'parallelism': f'batch shard x{world}, no data-path collective',
         },
+        'rccl_world': (dist.get_world_size() if use_dist else 1),
+        'dist_backend': (backend if use_dist else None),
+        'per_rank_ms_per_step': per_rank_ms,
+        'per_rank_image_checksum': sums,
+        'weights_s': t_weights,
+        'launch_thread_cores': pinned,
     }
-    # dominant kernel = the GEMM instantiation with the largest total sampled time
+    if stub:
+        print(json.dumps(out), flush=True)
+        dist and dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel = the GEMM instantiation with the largest sampled time
     if prof:
         dom = max(prof.values(), key=lambda r: r['ms'])
         eq = dom['flops'] / (dom['ms'] * 1e-3) / 1e12  # fp32-equivalent 2*M*N*K per launch / time
         split = dom['kernel'].startswith('gemm_split')
-        # The split-precision kernel's algorithm is three fp16 x fp16 partial products per
-        # fp32 multiply on v_mfma_f32_32x32x16_f16, so its matrix-core roofline is the
-        # dense 16-bit peak and its algorithmic work 3 * 2*M*N*K; the fp32-equivalent rate
-        # and its ratio to the fp32-MFMA peak are reported next to it.
+        # The split-precision kernel's algorithm is three fp16 x fp16 partial products per fp32
+        # multiply on v_mfma_f32_32x32x16_f16: its matrix-core roofline is the dense 16-bit peak and
+        # its executed work 3 * 2*M*N*K (`frac`); the reference's own FLOP count against the same
+        # peak is `frac_useful`.
         mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
         ach = eq * mult
         out['roofline'] = {
             'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': peak,
             'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+            'frac_basis': ('executed matrix instructions: 3 fp16 partial products per fp32 multiply'
+                           if split else 'fp32 matrix instructions = the reference FLOP count'),
+            'frac_useful': eq / peak,
             'fp32_equivalent_tflops': eq, 'frac_of_fp32_mfma_peak': eq / FP32_MFMA_PEAK_TFLOPS,
             'launches_sampled': dom['n'], 'avg_launch_us': 1000.0 * dom['ms'] / dom['n'],
             'flop_per_launch': mult * dom['flops'] / dom['n'],
@@ -278,31 +443,75 @@ def main():
                                      'avg_us': 1000.0 * v['ms'] / v['n']} for k, v in prof.items()},
         }
         out['roofline'].update(pmc_traffic(dom['kernel']))
-    # whole-path arithmetic rate against the same peak (26.17 TFLOP / image)
-    out['path_tflops'] = 26.17 * out['value'] / world
+    # ---- stage view (HIP events on the launch stream), incl. decode's compute AND HBM fractions
+    if stage_ms:
+        st = {k: {'ms_per_step': v} for k, v in stage_ms.items()}
+        b = batch_per_gpu
+        if 'sampler' in st:
+            fl = GFLOP_IMAGE['sampler_step'] * args.sample_steps * b * 1e9
+            st['sampler'].update(tflops_fp32_equivalent=fl / (stage_ms['sampler'] * 1e-3) / 1e12,
+                                 frac_useful_of_16bit_peak=fl / (stage_ms['sampler'] * 1e-3) / 1e12
+                                 / BF16_MFMA_PEAK_TFLOPS)
+        if 'refine_decode' in st:
+            t = stage_ms['refine_decode'] * 1e-3
+            fl = ((GFLOP_IMAGE['decode_hires'] if upscale else GFLOP_IMAGE['decode']) + GFLOP_IMAGE['refine']) * b * 1e9
+            by = DECODE_BYTES_IMAGE['hires' if upscale else 'parsing'] * b + DECODE_WEIGHT_BYTES
+            st['refine_decode'].update(
+                ms_per_image=1e3 * t / b, tflops=fl / t / 1e12,
+                compute_frac_of_fp32_mfma_peak=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                algorithmic_hbm_bytes=by, hbm_frac=by / t / (HBM_PEAK_TBS * 1e12),
+                note='SURVEY.md 8(d) algorithmic FLOPs / bytes (flash-style attention, fused norms); '
+                     'the stage is matrix-bound in fp32: at 100% of the fp32 MFMA peak its HBM fraction is 6.5%')
+        if 'pose_front_end' in st:
+            t = stage_ms['pose_front_end'] * 1e-3
+            fl = GFLOP_IMAGE['pose'] * b * 1e9
+            st['pose_front_end'].update(tflops=fl / t / 1e12,
+                                        compute_frac_of_fp32_mfma_peak=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+        out['stages'] = st
+    # whole-path arithmetic rate on the reference FLOP count
+    per_image = (GFLOP_IMAGE['sampler_step'] * args.sample_steps + GFLOP_IMAGE['tokenizer'] + GFLOP_IMAGE['refine']
+                 + (GFLOP_IMAGE['decode_hires'] if upscale else GFLOP_IMAGE['decode'])
+                 + (GFLOP_IMAGE['pose'] if args.config == 'pose' else 0.0)) / 1e3
+    out['path_tflops'] = per_image * out['value'] / world
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args.sample_steps, args.cpu_sampler_steps)
-    if world == 1 and not args.no_exact_fp32:
-        # the same step with the sampler's Linears / attention on the exact-fp32 matrix
-        # instructions instead of the split-precision kernels (T2H_SPLIT_GEMM=0), for reference
+        out['cpu_baseline'] = cpu_baseline(args.sample_steps, args.cpu_sampler_steps, args.cpu_repeats)
+    if world == 1 and not args.no_exact_fp32 and split_on:
+        # the same step with the sampler's Linears / attention on the exact-fp32 matrix instructions
+        # (T2H_SPLIT_GEMM=0): timing over >= 3 steps AND the parity of the default path against it
         from text2human_amd import engine
         fast = model.sampler_fn
         model.sampler_fn = engine.SamplerNet(model.P, model._tf_desc, opt['bert_n_head'], 'tf', split=False)
         one_step()
-        torch.cuda.synchronize()
+        sync()
         t1 = time.perf_counter()
-        one_step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
+        for _ in range(args.exact_steps):
+            top_x, u8_x = one_step()
+        sync()
+        dt = (time.perf_counter() - t1) / args.exact_steps
         model.sampler_fn = fast
-        out['exact_fp32_path'] = {'value': args.batch / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt,
+        out['exact_fp32_path'] = {'value': batch_per_gpu / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt,
                                   'note': 'sampler Linears and attention on v_mfma_f32_32x32x2_f32 (bitwise fp32 '
-                                          'fma chains); 1 warm-up + 1 timed step'}
+                                          f'fma chains); 1 warm-up + {args.exact_steps} timed steps'}
+        ts, tx = torch.stack(top), torch.stack(top_x)
+        diff = (u8.to(torch.int16) - u8_x.to(torch.int16)).abs()
+        n_tok = int((ts != tx).sum())
+        img_s, _, int_s = model.decode_indices(top, return_inter=True, upscale=upscale)
+        img_x, _, int_x = model.decode_indices(top_x, return_inter=True, upscale=upscale)
+        n_bot = sum(int((a['bot_lists'] != c['bot_lists']).sum()) for a, c in zip(int_s, int_x))
+        out['parity'] = {
+            'what': 'default split-precision step vs the exact-fp32 step, same batch, same seed, free-running '
+                    f'({args.sample_steps} steps, B={batch_per_gpu}); oracle-side parity on this configuration: '
+                    'tests/test_gpu_bench_parity.py',
+            'tokens_equal': n_tok == 0, 'token_mismatches': n_tok, 'tokens': int((ts >= 0).sum()),
+            'bot_indices_equal': n_bot == 0, 'bot_index_mismatches': n_bot,
+            'img_max_abs': float((img_s - img_x).abs().max()),
+            'images_u8_equal': bool(int(diff.max()) == 0), 'img_u8_max_abs': int(diff.max()),
+            'img_u8_frac_differing': float((diff != 0).float().mean()),
+        }
     if world == 1 and args.eager_gpu_baseline:
         out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, 16, dev)
     print(json.dumps(out), flush=True)
     if use_dist:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -139,6 +139,12 @@ typedef struct t2h_gemm_split_args {
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
+/* Sticky device-side overflow flag of every split-row producer (this GEMM's C_split / Vt
+ * epilogues, t2h_split_rows_f32, t2h_layernorm_split_f32, the attention outputs): raised when a
+ * value about to be written as split rows has |x| >= 65504 (fp16 planes would hold inf / NaN).
+ * Synchronises `stream`, returns 1 if the flag was raised since the last reset, 0 if not, < 0 on
+ * error; reset != 0 clears it.  The host side checks it once per sampling run and raises. */
+int t2h_split_overflow(int32_t reset, void* stream);
 int t2h_gemm_split_force_config(int cfg); /* tuning: 0 128x64/4 waves, 1 128x128/8 waves, -1 auto */
 /* fp32 [rows, C] (row stride ldx) -> split rows */
 int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);

@@ -1,0 +1,56 @@
+"""bench.py's own multi-rank code path (shard of the global batch, per-rank seed, weight
+broadcast from rank 0, barrier + max-over-ranks timing, per-rank gathers, ONE JSON line on
+rank 0) executed with world_size 2 on gloo / CPU through torch.distributed.run, exactly as the
+driver launches it on GPUs -- with `--stub-model` standing in for the HIP model."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _run(nproc, extra=()):
+    env = dict(os.environ, T2H_NO_PIN='0', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'),
+           '--gpus', str(nproc), '--steps', '3', '--warmup', '1', '--stub-model', '--batch', '3', *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f'stdout must hold exactly one JSON line, got: {lines}'
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_gloo():
+    out = _run(2)
+    assert out['n_gpus'] == 2 and out['rccl_world'] == 2 and out['dist_backend'] == 'gloo'
+    assert out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['config']['global_batch'] == 6
+    assert len(out['per_rank_ms_per_step']) == 2 and all(t > 0 for t in out['per_rank_ms_per_step'])
+    # max over ranks: the reported step time is not below any rank's own
+    assert out['ms_per_step'] >= max(out['per_rank_ms_per_step']) - 1e-6
+    assert abs(out['value'] - 6 * 1000.0 / out['ms_per_step']) < 1e-6 * out['value']
+    # every rank worked on ITS shard (different data -> different checksums) with broadcast weights
+    cs = out['per_rank_image_checksum']
+    assert len(cs) == 2 and cs[0] != cs[1]
+    # the shards are those of the single-process run over the same global batch
+    one = _run(1, ('--batch', '6'))
+    assert one['rccl_world'] == 1 and len(one['per_rank_image_checksum']) == 1
+
+
+def test_broadcast_state_dicts_roundtrip_single_process():
+    from text2human_amd import shard
+    sds = {'a': {'w': torch.randn(3, 4), 'i': torch.arange(5)}}
+    assert shard.broadcast_state_dicts(sds, 1, torch.device('cpu')) is sds

@@ -14,3 +14,38 @@ void t2h_set_error(const char* fmt, ...) {
 
 extern "C" int t2h_version(void) { return 100; }
 extern "C" const char* t2h_last_error(void) { return g_err; }
+
+// ---- sticky overflow flag of the split-precision producers (common.h) ----
+#include <mutex>
+
+namespace {
+constexpr int kMaxDev = 64;
+int* g_ovf[kMaxDev];
+std::mutex g_ovf_mu;
+}  // namespace
+
+int* t2h_split_overflow_flag_ptr() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  std::lock_guard<std::mutex> lk(g_ovf_mu);
+  if (!g_ovf[dev]) {
+    int* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(int)) != hipSuccess) return nullptr;
+    g_ovf[dev] = p;
+  }
+  return g_ovf[dev];
+}
+
+extern "C" int t2h_split_overflow(int32_t reset, void* stream) {
+  int* p = t2h_split_overflow_flag_ptr();
+  T2H_REQUIRE(p != nullptr, "t2h_split_overflow: cannot allocate the device flag");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int v = 0;
+  if (hipMemcpyAsync(&v, p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      (reset && hipMemsetAsync(p, 0, sizeof(int), s) != hipSuccess) || hipStreamSynchronize(s) != hipSuccess) {
+    t2h_set_error("t2h_split_overflow: %s", hipGetErrorString(hipGetLastError()));
+    return T2H_ERR_LAUNCH;
+  }
+  return v != 0 ? 1 : 0;
+}

@@ -35,7 +35,7 @@ constexpr int KV_TILE = KT * K_LD + KT * V_LD;  // floats per (K,V) tile pair
 
 __global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
                                                   float* __restrict__ y, int T, int C,
-                                                  int n_head, uint16_t* __restrict__ y_split) {
+                                                  int n_head, uint16_t* __restrict__ y_split, int* ovf) {
   // [2 key halves][K tile | V tile]; reused at the end: [0, 8192) partial O of
   // the second key half, [8192, 8192 + 4*32*O_LD) output transpose staging.
   __shared__ __attribute__((aligned(16))) float smem[2 * KV_TILE];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
         *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
         *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
       }
-      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb);
+      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
     }
   }
 }
@@ -276,7 +276,8 @@ __device__ __forceinline__ void half_barrier(int* ctr, int target, int lane) {
 
 __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restrict__ qk, int ld_cols,
                                                         const uint16_t* __restrict__ vt, float* __restrict__ y,
-                                                        uint16_t* __restrict__ y_split, int T, int C, int n_head) {
+                                                        uint16_t* __restrict__ y_split, int T, int C, int n_head,
+                                                        int* ovf) {
   // two (K, Vt) tile pairs; reused at the end for the merge + output transpose staging
   constexpr int SMEM_B = 2 * SKV_TILE > (4 * 32 * 64 + 4 * 32 * O_LD) * 4 ? 2 * SKV_TILE
                                                                            : (4 * 32 * 64 + 4 * 32 * O_LD) * 4;
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
         *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
         *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
       }
-      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb);
+      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
     }
   }
 #ifdef T2H_MHA_TIMING
@@ -537,7 +538,7 @@ extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int3
   const int C = n_head * HD;
   dim3 grid((T / QB) * n_head * B), block(512);
   hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv, y, T, C, n_head,
-                     static_cast<uint16_t*>(nullptr));
+                     static_cast<uint16_t*>(nullptr), static_cast<int*>(nullptr));
   T2H_CHECK_LAUNCH("t2h_mha_noncausal_f32");
   return T2H_OK;
 }
@@ -550,8 +551,10 @@ extern "C" int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, 
   T2H_REQUIRE(t2h_aligned16(qkv) && t2h_aligned16(y_split), "t2h_mha_noncausal_split_f32: 16-byte alignment");
   const int C = n_head * HD;
   dim3 grid((T / QB) * n_head * B), block(512);
+  int* ovf = t2h_split_overflow_flag_ptr();
+  T2H_REQUIRE(ovf != nullptr, "t2h_mha_noncausal_split_f32: no overflow flag");
   hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv,
-                     static_cast<float*>(nullptr), T, C, n_head, y_split);
+                     static_cast<float*>(nullptr), T, C, n_head, y_split, ovf);
   T2H_CHECK_LAUNCH("t2h_mha_noncausal_split_f32");
   return T2H_OK;
 }
@@ -568,8 +571,10 @@ extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, cons
                   (!y_split || t2h_aligned16(y_split)),
               "t2h_mha_split_f32: 16-byte alignment");
   dim3 grid((T / QB) * n_head * B), block(512);
+  int* ovf = t2h_split_overflow_flag_ptr();
+  T2H_REQUIRE(ovf != nullptr, "t2h_mha_split_f32: no overflow flag");
   hipLaunchKernelGGL(mha_split_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt, y,
-                     y_split, T, C, n_head);
+                     y_split, T, C, n_head, ovf);
   T2H_CHECK_LAUNCH("t2h_mha_split_f32");
   return T2H_OK;
 }

@@ -11,6 +11,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void t2h_set_error(const char* fmt, ...);
 
+// Device-resident sticky flag of the split-precision producers (api.hip): set when a value
+// that is about to be written as split rows does not fit fp16's range (|x| >= 65504 would
+// turn into inf / NaN planes).  Read back by t2h_split_overflow().  One int per device,
+// allocated on first use; NULL only if that allocation failed (reported by the caller).
+int* t2h_split_overflow_flag_ptr();
+
 #define T2H_REQUIRE(cond, ...)                 \
   do {                                         \
     if (!(cond)) {                             \
@@ -79,9 +85,24 @@ __device__ __forceinline__ void t2h_split2(float x, _Float16& hi, _Float16& lo) 
   lo = (_Float16)((x - (float)hi) * T2H_SPLIT_LO_SCALE);
 }
 
+// raises the sticky overflow flag if any of the 8 values leaves the split-row domain
+// (|x| >= 65504, +-inf).  NaN inputs can only descend from an earlier, already flagged
+// overflow (inf - inf) and are not looked for.
+__device__ __forceinline__ void t2h_split_guard8(int* ovf, f32x4 va, f32x4 vb) {
+  const float m = fmaxf(fmaxf(fmaxf(fabsf(va[0]), fabsf(va[1])), fmaxf(fabsf(va[2]), fabsf(va[3]))),
+                        fmaxf(fmaxf(fabsf(vb[0]), fabsf(vb[1])), fmaxf(fabsf(vb[2]), fabsf(vb[3]))));
+  if (m >= 65504.0f) atomicOr(ovf, 1);
+}
+__device__ __forceinline__ void t2h_split_guard4(int* ovf, f32x4 v) {
+  const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  if (m >= 65504.0f) atomicOr(ovf, 1);
+}
+
 // writes 8 consecutive columns c0..c0+7 (c0 % 8 == 0) of `row` as split rows: one 16-byte
 // store per plane
-__device__ __forceinline__ void t2h_store_split8(uint16_t* base, int64_t row, int C, int c0, f32x4 va, f32x4 vb) {
+__device__ __forceinline__ void t2h_store_split8(uint16_t* base, int64_t row, int C, int c0, f32x4 va, f32x4 vb,
+                                                 int* ovf) {
+  t2h_split_guard8(ovf, va, vb);
   t2h_f16x8 h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -100,7 +121,8 @@ __device__ __forceinline__ void t2h_store_split8(uint16_t* base, int64_t row, in
 }
 
 // writes 4 consecutive columns c0..c0+3 (c0 % 4 == 0) of `row` as split rows
-__device__ __forceinline__ void t2h_store_split4(uint16_t* base, int64_t row, int C, int c0, f32x4 v) {
+__device__ __forceinline__ void t2h_store_split4(uint16_t* base, int64_t row, int C, int c0, f32x4 v, int* ovf) {
+  t2h_split_guard4(ovf, v);
   t2h_f16x4 h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {

@@ -113,7 +113,7 @@ __device__ __forceinline__ f32x4 gelu_erf_v(f32x4 v) {
 // the result is deterministic.  It gives a tile that only fills the chip at one block
 // per CU (N = 512 at M = 4096) two waves per SIMD without shrinking the wave tile.
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, bool GLDS = false>
-__global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p) {
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p, int* const ovf) {
   constexpr int NT = 64 * WARPS_M * WARPS_N;  // threads per K group
   constexpr int NWG = WARPS_M * WARPS_N;      // waves per K group
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -489,6 +489,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
         va += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + cl * OT_LD + ra);
         vb += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + cl * OT_LD + ra + 8);
       }
+      t2h_split_guard8(ovf, va, vb);
       t2h_f16x8 vh, vl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -575,19 +576,19 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = va;
       *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col + 4) = vb;
     }
-    if (p.C_split) t2h_store_split8(p.C_split, row, p.N, col, va, vb);
+    if (p.C_split) t2h_store_split8(p.C_split, row, p.N, col, va, vb, ovf);
   }
 }
 
 // fp32 [rows, C] (ld) -> split rows; one thread per 4 consecutive columns
 __global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ out, int64_t total,
-                                  int C) {
+                                  int C, int* ovf) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over rows * C/4
   if (i >= total) return;
   const int q = C >> 2;
   const int64_t row = i / q;
   const int c0 = (int)(i - row * q) * 4;
-  t2h_store_split4(out, row, C, c0, *reinterpret_cast<const f32x4*>(x + row * ldx + c0));
+  t2h_store_split4(out, row, C, c0, *reinterpret_cast<const f32x4*>(x + row * ldx + c0), ovf);
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1, bool GLDS = false>
@@ -599,8 +600,10 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
     T2H_REQUIRE(a.vt_col0 % BN == 0, "t2h_gemm_split_f32: vt_col0=%d must be a multiple of the %d-column tile",
                 a.vt_col0, BN);
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
+  int* ovf = t2h_split_overflow_flag_ptr();
+  T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
   hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, GLDS>), grid,
-                     dim3(64 * WARPS_M * WARPS_N * KS), 0, s, a);
+                     dim3(64 * WARPS_M * WARPS_N * KS), 0, s, a, ovf);
   T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
   return T2H_OK;
 }
@@ -667,8 +670,10 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
 extern "C" int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream) {
   T2H_REQUIRE(x && out && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0, "t2h_split_rows_f32: bad arguments");
   const int64_t total = rows * (C / 4);
+  int* ovf = t2h_split_overflow_flag_ptr();
+  T2H_REQUIRE(ovf != nullptr, "t2h_split_rows_f32: no overflow flag");
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, ldx, out, total, C);
+                     static_cast<hipStream_t>(stream), x, ldx, out, total, C, ovf);
   T2H_CHECK_LAUNCH("t2h_split_rows_f32");
   return T2H_OK;
 }

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         float* __restrict__ y, int rows,
-                                                        float eps) {
+                                                        float eps, int* ovf) {
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     // plane) -- the even lane slab i, the odd lane slab i+1
     static_assert(VPL % 2 == 0 || VPL == 1, "pairwise slab exchange");
     if (VPL == 1) {
-      t2h_store_split4(reinterpret_cast<uint16_t*>(y), row, C, lane * 4, v[0]);
+      t2h_store_split4(reinterpret_cast<uint16_t*>(y), row, C, lane * 4, v[0], ovf);
     } else {
 #pragma unroll
       for (int i = 0; i < VPL; i += 2) {
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           send[e] = odd ? v[i][e] : v[i + 1][e];
           recv[e] = __shfl_xor(send[e], 1, 64);
         }
-        if (!odd) t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, i * 256 + lane * 4, v[i], recv);
-        else t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, (i + 1) * 256 + (lane - 1) * 4, recv, v[i + 1]);
+        if (!odd) t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, i * 256 + lane * 4, v[i], recv, ovf);
+        else t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, (i + 1) * 256 + (lane - 1) * 4, recv, v[i + 1], ovf);
       }
     }
   }
@@ -202,9 +202,9 @@ extern "C" int t2h_layernorm_f32(const float* x, const float* gamma, const float
               "t2h_layernorm_f32: 16-byte alignment");
   dim3 grid((rows + 3) / 4), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (C == 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
-  else if (C == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
-  else if (C == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+  if (C == 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr));
+  else if (C == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr));
+  else if (C == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr));
   else {
     t2h_set_error("t2h_layernorm_f32: C=%d unsupported (256/512/1024)", C);
     return T2H_ERR_UNSUPPORTED;
@@ -223,9 +223,11 @@ extern "C" int t2h_layernorm_split_f32(const float* x, const float* gamma, const
   dim3 grid((rows + 3) / 4), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* y = reinterpret_cast<float*>(y_split);
-  if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps);
-  else if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps);
-  else if (C == 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps);
+  int* ovf = t2h_split_overflow_flag_ptr();
+  T2H_REQUIRE(ovf != nullptr, "t2h_layernorm_split_f32: no overflow flag");
+  if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
+  else if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
+  else if (C == 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
   else {
     t2h_set_error("t2h_layernorm_split_f32: C=%d unsupported (256/512/1024)", C);
     return T2H_ERR_UNSUPPORTED;

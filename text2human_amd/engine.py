@@ -9,7 +9,7 @@ HBM.  PyTorch only allocates tensors and provides the stream.
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU, PRO_NONE, PRO_SWISH
 
 
@@ -319,8 +319,23 @@ class TorchDeviceNoise:
         return torch.empty(shape, device=self.device).exponential_(1.0)
 
 
+class SplitOverflowError(_lib.T2HError):
+    """An activation of the split-precision sampler left fp16's range."""
+
+
+def check_split_overflow(what='sampler'):
+    """Raises if a split-row producer flagged |x| >= 65504 since the last check (the fp16
+    planes would hold inf / NaN).  There is deliberately no silent fallback: the caller reruns
+    with T2H_SPLIT_GEMM=0 (exact-fp32 matrix instructions)."""
+    if ops.split_overflow(reset=True):
+        raise SplitOverflowError(
+            f'{what}: an activation reached |x| >= 65504, outside the range of the 2 x fp16 split '
+            'representation (include/t2h_hip.h); the result is invalid.  Rerun with T2H_SPLIT_GEMM=0 '
+            '(exact-fp32 kernels).')
+
+
 def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise=None,
-                  n_books=18):
+                  n_books=18, step_hook=None):
     """BaseSampleModel.sample_fn (models/sample_model.py:256-328) on device.
 
     Per step: one tiny kernel does the mask algebra and counts the changed
@@ -328,10 +343,18 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     heads draw noise (the reference's data-dependent `if`, :301-302, which
     gates RNG consumption) -- it is issued before the transformer launches so
     the host wait overlaps the GPU work; then the texture-routed sampling tail
-    runs once per active head.  Returns int64 [18, B*T] (-1 off-texture)."""
+    runs once per active head.  Returns int64 [18, B*T] (-1 off-texture).
+
+    step_hook(t, x_t, out) (tests only) runs after every step and may overwrite x_t in
+    place, e.g. to teacher-force the reference's trajectory."""
     P, nm = net.P, net.name
     B, T = segm_tok.shape
     dev = segm_tok.device
+    # the reference indexes texture_emb / head_list with these ids and raises on a bad one
+    # (transformer_arch.py:262, sample_model.py:300-317); here they index device arrays
+    lo, hi = int(tex_tok.min()), int(tex_tok.max())
+    if lo < 0 or hi >= n_books:
+        raise _lib.T2HError(f'texture ids must lie in [0, {n_books}), got [{lo}, {hi}]')
     noise = noise or TorchDeviceNoise(dev)
     n = B * T
     x_t = torch.full((B, T), mask_id, dtype=torch.int64, device=dev)
@@ -360,6 +383,10 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
         expo = {cb: noise.exponential(t, cb, (n, n_class)).to(dev, torch.float32).contiguous() for cb in active}
         ops.sample_heads(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'], expo, rows,
                          int(counts_host[n_books]), tex_flat, temp, x_t, out)
+        if step_hook is not None:
+            step_hook(t, x_t, out)
+    if net.split:
+        check_split_overflow('index sampler')
     return out
 
 

@@ -292,6 +292,15 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     return out if out is not None else out_split
 
 
+def split_overflow(reset=True):
+    """True if any split-row producer met a value outside fp16's range (|x| >= 65504) since
+    the last reset (sticky device flag, include/t2h_hip.h); synchronises the current stream."""
+    r = _lib.load().t2h_split_overflow(int(bool(reset)), _stream())
+    if r < 0:
+        check(r, 't2h_split_overflow')
+    return bool(r)
+
+
 def vt_empty(B, n_head, T, device, hd=64):
     """Transposed value planes [B][H][2][hd][T] fp16 (as int16) for mha_split."""
     return torch.empty(B, n_head, 2, hd, T, dtype=torch.int16, device=device)

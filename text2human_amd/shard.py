@@ -58,3 +58,48 @@ def gather_images(u8, world, dst=0):
     if rank != dst:
         return None
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+
+
+def gather_floats(value, world, device):
+    """One float per rank -> list on every rank (per-rank step times, checksums)."""
+    if world == 1:
+        return [float(value)]
+    import torch.distributed as dist
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    bufs = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, mine)
+    return [float(b.item()) for b in bufs]
+
+
+def broadcast_state_dicts(sds, world, device, src=0):
+    """Checkpoints are read / synthesised ONCE, on rank `src`, and reach the other ranks of the
+    node as one flat fp32 buffer over RCCL/xGMI ("optional broadcast of repacked
+    weights from rank 0 at init") instead of N processes each re-reading or re-synthesising ~0.9 GB
+    on the host.  `sds`: dict module -> state_dict on `src`, ignored (may be None) elsewhere.
+    Returns the same structure with CPU tensors on every rank."""
+    if world == 1:
+        return sds
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    meta = [None]
+    if rank == src:
+        meta[0] = [(m, k, tuple(v.shape), str(v.dtype)) for m, sd in sds.items() for k, v in sd.items()]
+    dist.broadcast_object_list(meta, src=src)
+    meta = meta[0]
+    numel = [int(torch.Size(shape).numel()) for _, _, shape, _ in meta]
+    flat = torch.empty(sum(numel), dtype=torch.float64 if any(d == 'torch.float64' for *_, d in meta)
+                       else torch.float32, device=device)
+    if rank == src:
+        off = 0
+        for (m, k, _, _), n in zip(meta, numel):
+            flat[off:off + n].copy_(sds[m][k].reshape(-1))
+            off += n
+    dist.broadcast(flat, src=src)
+    if rank == src:
+        return sds
+    host = flat.cpu()
+    out, off = {}, 0
+    for (m, k, shape, dtype), n in zip(meta, numel):
+        out.setdefault(m, {})[k] = host[off:off + n].view(shape).to(getattr(torch, dtype.split('.')[-1]))
+        off += n
+    return out
