@@ -68,6 +68,19 @@ __device__ __forceinline__ float fast_exp(float x) {
   return fmaf(r, e * 0.693147180559945309417f, r);
 }
 
+// ---- 16-byte write-through store (global_store_dwordx4 ... sc1) for results that are written
+// once and consumed by a LATER kernel (split rows, Vt planes).  A plain store leaves the line dirty
+// in this XCD's L2, to be written back at the end of the kernel -- after the epilogue, with nothing
+// to overlap -- although no other XCD can use that copy; sc1 sends the bytes out during the epilogue.
+// Measured on the fc1 shape (33.5 MB of split rows): 35.7 -> 33.0 us per launch, q|k|v 29.4 -> 28.1
+// (profiles/r02_store_flavour.log).  NOT for the fp32 residual stream, which proj / fc2 read and
+// rewrite in place: there sc1 costs +1.5-2 us.
+template <typename V>
+__device__ __forceinline__ void t2h_store16_wt(void* ptr, const V& v) {
+  static_assert(sizeof(V) == 16, "16-byte vector");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+}
+
 // ---- split-row helpers shared by the producers of t2h_gemm_split_f32 operands.
 // An fp32 value is carried as two fp16 planes, x = h + l * 2^-11 with h = fp16(x) and
 // l = fp16((x - h) * 2^11) (22 significant bits; the 2^11 keeps the residual out of
@@ -116,8 +129,8 @@ __device__ __forceinline__ void t2h_store_split8(uint16_t* base, int64_t row, in
   }
   char* d = reinterpret_cast<char*>(base) + row * (int64_t)(C / 32) * T2H_SPLIT_TILE_B +
             (c0 >> 5) * T2H_SPLIT_TILE_B + (c0 & 31) * 2;
-  *reinterpret_cast<t2h_f16x8*>(d) = h;
-  *reinterpret_cast<t2h_f16x8*>(d + T2H_SPLIT_PLANE_B) = l;
+  t2h_store16_wt(d, h);
+  t2h_store16_wt(d + T2H_SPLIT_PLANE_B, l);
 }
 
 // writes 4 consecutive columns c0..c0+3 (c0 % 4 == 0) of `row` as split rows

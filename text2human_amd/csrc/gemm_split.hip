@@ -107,6 +107,13 @@ __device__ __forceinline__ f32x4 gelu_erf_v(f32x4 v) {
   return f32x4{a[0], a[1], b[0], b[1]};
 }
 
+#ifdef T2H_GEMM_TIMING
+__device__ long long* g1_timing = nullptr;  // debug builds only (tools/gemm_phase_timing.py)
+#define G1_MARK(i) do { if (g1_timing && threadIdx.x == 0) g1_timing[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define G1_MARK(i) do { } while (0)
+#endif
+
 // KS = 2: in-block K split.  Two wave groups of WARPS_M x WARPS_N waves each own the
 // whole BM x BN tile, their own pair of LDS tile buffers and every second K tile (group
 // g takes tiles 2s + g); the partial sums meet in LDS in the epilogue, group 0 first, so
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM_B + BM * 8];  // + (mean, rstd) of the BM rows
 
+  G1_MARK(0);
   const int kg = KS == 1 ? 0 : (int)threadIdx.x / NT;  // K group
   const int tid = threadIdx.x - kg * NT;
   const int lane = tid & 63, wave = tid >> 6;  // wave index inside the group
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   __builtin_amdgcn_sched_barrier(0);
   issue(set0{}, 2);
   __syncthreads();
+  G1_MARK(1);
 
   // partial products (A plane, B plane, accumulator): (l,h) (h,l) -> acc[1], (h,h) -> acc[0]
   constexpr int PA[3] = {1, 0, 0};
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     __syncthreads();                                  // the tile buffers are reused by the epilogue
   }
 
+  G1_MARK(2);
   // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (r&3) +
   // 8*(r>>2) + 4*(lane>>5)) are transposed through the (now idle) LDS so that every
   // lane owns 4 CONSECUTIVE columns of a row: residual loads and fp32 stores become
@@ -503,8 +513,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       }
       const int cc = col - p.vt_col0, head = cc / p.vt_hd, d = cc - head * p.vt_hd;
       uint16_t* dstp = p.Vt + ((((int64_t)b * n_vh + head) * 2) * p.vt_hd + d) * p.vt_T + key0 + 8 * u;
-      *reinterpret_cast<t2h_f16x8*>(dstp) = vh;
-      *reinterpret_cast<t2h_f16x8*>(dstp + (int64_t)p.vt_hd * p.vt_T) = vl;
+      t2h_store16_wt(dstp, vh);
+      t2h_store16_wt(dstp + (int64_t)p.vt_hd * p.vt_T, vl);
     }
     return;
   }
@@ -578,6 +588,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     }
     if (p.C_split) t2h_store_split8(p.C_split, row, p.N, col, va, vb, ovf);
   }
+#ifdef T2H_GEMM_TIMING
+  G1_MARK(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G1_MARK(4);
+#endif
 }
 
 // fp32 [rows, C] (ld) -> split rows; one thread per 4 consecutive columns
@@ -611,6 +626,12 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
 int g_force_split_cfg = -1;
 
 }  // namespace
+
+#ifdef T2H_GEMM_TIMING
+extern "C" int t2h_debug_set_gemm1_timing_buffer(void* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g1_timing), &dev_ptr, sizeof(void*));
+}
+#endif
 
 extern "C" int t2h_gemm_split_force_config(int cfg) {
   const int old = g_force_split_cfg;

@@ -182,6 +182,9 @@ __device__ __forceinline__ void sample_row(float* lds, int row, const float* __r
         best = red[k];
         best_j = redj[k];
       }
+    // all-NaN scores (only after a flagged split-precision overflow upstream): keep the token id
+    // inside the embedding table so the run reaches the host-side overflow check instead of faulting
+    if (best_j >= n_class) best_j = 0;
     x_t[row] = (int64_t)best_j + (int64_t)n_class * head;
     out_idx[row] = best_j;
   }

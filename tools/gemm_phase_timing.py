@@ -1,0 +1,76 @@
+"""Where does a split-GEMM launch spend its time?  Debug build (-DT2H_GEMM_TIMING) with
+s_memrealtime stamps (100 MHz) per workgroup: entry, prologue done, main loop done, epilogue
+stores issued, stores acknowledged.  Prints the median phase lengths, the dispatch skew and the
+span first-entry -> last-ack next to the event-timed launch.  GPU only.
+
+    python tools/gemm_phase_timing.py [cfgs=4,6,8] [batch=8]
+"""
+import ctypes
+import os
+import statistics
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from text2human_amd._lib import GemmSplitArgs  # noqa: E402
+
+csrc = os.path.join(ROOT, 'text2human_amd', 'csrc')
+so = '/tmp/libt2h_gemm_timing.so'
+subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-comment',
+                f'-I{ROOT}/include', '-DT2H_GEMM_TIMING', os.path.join(csrc, 'api.hip'),
+                os.path.join(csrc, 'gemm_split.hip'), '-o', so], check=True)
+lib = ctypes.CDLL(so)
+CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 else [4, 6]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+M = 512 * B
+g0 = torch.Generator().manual_seed(0)
+for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536, 512, False, False),
+                                    proj=(512, 512, False, True), fc2=(512, 2048, False, True)).items():
+    a = (torch.randn(M * k * 2, generator=g0) * 0.5).half().view(torch.int16).cuda()
+    w = (torch.randn(n * k * 2, generator=g0) * 0.05).half().view(torch.int16).cuda()
+    out = torch.zeros(M, n, device='cuda')
+    osp = torch.empty(M * n * 2, dtype=torch.int16, device='cuda')
+    bias = torch.randn(n, generator=g0).cuda()
+    g = GemmSplitArgs()
+    g.A, g.B, g.bias = a.data_ptr(), w.data_ptr(), bias.data_ptr()
+    g.M, g.N, g.K, g.ldc, g.ldr = M, n, k, n, n
+    if res:
+        g.C, g.residual = out.data_ptr(), out.data_ptr()
+    else:
+        g.C_split = osp.data_ptr()
+    g.epi_act = 1 if gelu else 0
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for cfg in CFGS:
+        lib.t2h_gemm_split_force_config(cfg)
+        tb = torch.zeros(8 * 4096, dtype=torch.int64, device='cuda')
+        setter = lib.t2h_debug_set_gemm1_timing_buffer
+        setter(ctypes.c_void_p(0))
+        for _ in range(3):
+            assert lib.t2h_gemm_split_f32(ctypes.byref(g), st) == 0, name
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            lib.t2h_gemm_split_f32(ctypes.byref(g), st)
+        e1.record()
+        torch.cuda.synchronize()
+        t_evt = e0.elapsed_time(e1) / 20 * 1e3
+        setter(ctypes.c_void_p(tb.data_ptr()))
+        lib.t2h_gemm_split_f32(ctypes.byref(g), st)
+        torch.cuda.synchronize()
+        setter(ctypes.c_void_p(0))
+        t = tb.view(-1, 8).cpu()
+        t = t[t[:, 0] != 0].double() * 0.01  # us
+        nb = t.shape[0]
+        first = t[:, 0].min().item()
+        med = lambda v: statistics.median(v.tolist())
+        print(f'{name:8s} cfg{cfg:2d}: launch {t_evt:6.1f} us | {nb:4d} blocks | entry skew med {med(t[:, 0] - first):5.2f} '
+              f'max {(t[:, 0] - first).max().item():5.2f} | prologue {med(t[:, 1] - t[:, 0]):5.2f} | main loop '
+              f'{med(t[:, 2] - t[:, 1]):5.2f} (max {(t[:, 2] - t[:, 1]).max().item():5.2f}) | epilogue issue '
+              f'{med(t[:, 3] - t[:, 2]):5.2f} | store ack {med(t[:, 4] - t[:, 3]):5.2f} | first entry -> last ack '
+              f'{(t[:, 4].max().item() - first):6.2f} | last main-loop end {(t[:, 2].max().item() - first):6.2f}',
+              flush=True)
+    lib.t2h_gemm_split_force_config(-1)
