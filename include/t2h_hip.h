@@ -78,15 +78,6 @@ typedef struct t2h_gemm_args {
   int32_t ups;            /* 1: input is nearest-upsampled x2 on the fly */
   int32_t batch;          /* >=1: independent problems (blockIdx.z) */
   int64_t strideA, strideB, strideC; /* element strides between problems */
-  /* Fused LayerNorm (transformer_arch.py:80-81,93-95): rows of A are normalised on
-   * the fly, a' = (a - mean_r) * rstd_r, from per-row partial statistics
-   * [M][K/32][2] = (sum, sum of squares) per 32-column slab; gamma/beta are folded
-   * into B / bias by the caller.  Plain GEMM (a_mode 0, no tables, no b_trans). */
-  const float* ln_stats_in;
-  /* If set, the epilogue writes the same statistics of the OUTPUT rows,
-   * [M][N/32][2], for the next GEMM (N % 32 == 0). */
-  float* ln_stats_out;
-  float ln_eps;
 } t2h_gemm_args;
 
 int t2h_gemm_f32(const t2h_gemm_args* args, void* stream);
@@ -124,18 +115,6 @@ typedef struct t2h_gemm_split_args {
    * P*V matrix instruction contracts them.  NULL = off. */
   uint16_t* Vt;
   int32_t vt_col0, vt_T, vt_hd;
-  /* LayerNorm folded around the Linear (nn.LayerNorm + nn.Linear of Block.forward,
-   * transformer_arch.py:93-98).  Producer side, ln_part_out != NULL: also writes, per output
-   * row and 32-column slab, (sum, sum of squares) of the FINAL values to
-   * ln_part_out[M][N/32][2].  Consumer side, ln_part != NULL: A holds the un-normalised rows,
-   * B the weights scaled by gamma, bias = b + W beta, ln_colsum[j] = sum_k B[j][k]; the kernel
-   * returns rstd_i (acc_ij - mean_i ln_colsum[j]) + bias[j] with mean / rstd over K from the
-   * ln_parts partials of row i (eps = ln_eps), i.e. Linear(LayerNorm(x)). */
-  const float* ln_part;
-  const float* ln_colsum;
-  float* ln_part_out;
-  int32_t ln_parts;
-  float ln_eps;
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
@@ -145,7 +124,7 @@ int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
  * Synchronises `stream`, returns 1 if the flag was raised since the last reset, 0 if not, < 0 on
  * error; reset != 0 clears it.  The host side checks it once per sampling run and raises. */
 int t2h_split_overflow(int32_t reset, void* stream);
-int t2h_gemm_split_force_config(int cfg); /* tuning: 0 128x64/4 waves, 1 128x128/8 waves, -1 auto */
+int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..6, -1 auto */
 /* fp32 [rows, C] (row stride ldx) -> split rows */
 int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);
 /* producers that emit split rows directly: LayerNorm (transformer_arch.py:93-95)
@@ -175,11 +154,6 @@ int t2h_groupnorm_tables_f32(const float* x, int32_t ldx, const float* gamma,
                              const float* beta, float* scale, float* shift,
                              int32_t n_img, int32_t HW, int32_t C, int32_t groups,
                              float eps, void* workspace, void* stream);
-
-/* per-row, per-32-column-slab (sum, sum of squares) of x[rows, C] -> stats
- * [rows][C/32][2]: seeds the fused-LayerNorm statistics (t2h_gemm_args.ln_stats_in)
- * for a tensor that did not come out of a GEMM epilogue (the embedding sum) */
-int t2h_row_stats_f32(const float* x, float* stats, int32_t rows, int32_t C, void* stream);
 
 /* in-place row softmax of [rows, n] (AttnBlock, vqgan_arch.py:647) */
 int t2h_softmax_rows_f32(float* x, int32_t rows, int32_t n, int32_t ld, void* stream);

@@ -30,7 +30,7 @@ def test_split_rows_carry_22_bits_and_match_the_host_pack():
     assert ((back - x).abs() <= x.abs() * 2.0**-21 + 2.0**-36).all()
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('M,N,K', [(4096, 512, 512), (1024, 1536, 512), (512, 512, 2048), (130, 96, 64),
                                    (40, 32, 32)])
 def test_gemm_split(cfg, M, N, K):
@@ -96,7 +96,7 @@ def _pack_vt_host(v, B, T, H):
     return out.view(torch.int16)
 
 
-@pytest.mark.parametrize('cfg', [0, 2, 3, 6, 7])
+@pytest.mark.parametrize('cfg', [0, 2, 3, 4, 6])
 def test_gemm_split_routes_value_columns_to_transposed_planes(cfg):
     B, T, H, C = 2, 512, 8, 512
     M = B * T
@@ -161,60 +161,3 @@ def test_sampler_net_split_mha_on_and_off_agree_with_oracle():
     ea, eb = (ln(a) - ref).abs().max().item(), (ln(b) - ref).abs().max().item()
     assert ea < 1e-4 and eb < 1e-4, (ea, eb)
     assert eb < 3 * ea + 1e-6, f'split attention path error {eb:.2e} vs fp32 attention {ea:.2e}'
-
-
-@pytest.mark.parametrize('cfg', [0, 6])
-def test_gemm_split_folded_layernorm_producer_and_consumer(cfg):
-    """producer: partial (sum, sum of squares) per row and 32-column slab of its final output;
-    consumer: Linear(LayerNorm(x)) from the raw rows, gamma-scaled weights and those partials"""
-    M, C, N = 1024, 512, 768
-    y, wp, bp = _rnd(M, C, seed=30) * 1.2, _rnd(C, C, seed=31, scale=0.05), _rnd(C, seed=32) * 0.1
-    x_old = _rnd(M, C, seed=33) * 0.7 + 0.3                      # residual stream with a mean
-    g, be = _rnd(C, seed=34) * 0.2 + 1.0, _rnd(C, seed=35) * 0.1
-    w, b = _rnd(N, C, seed=36, scale=0.06), _rnd(N, seed=37) * 0.1
-    lib = _lib.load()
-    lib.t2h_gemm_split_force_config(cfg)
-    try:
-        x_new = x_old.clone().to(DEV)
-        xs = ops.split_rows_empty(M, C, DEV)
-        part = torch.empty(M, C // 32, 2, device=DEV)
-        ops.gemm_split(ops.split_rows(y.to(DEV)), ops.pack_split_rows_host(wp).to(DEV), M, C, C, out=x_new,
-                       out_split=xs, bias=bp.to(DEV), residual=x_new, ln_part_out=part)
-    finally:
-        lib.t2h_gemm_split_force_config(-1)
-    xr = x_new.cpu()
-    assert torch.equal(xs.cpu(), ops.pack_split_rows_host(xr).view_as(xs.cpu()))
-    slabs = xr.view(M, C // 32, 32).double()
-    assert torch.allclose(part[:, :, 0].cpu().double(), slabs.sum(2), rtol=1e-5, atol=1e-5)
-    assert torch.allclose(part[:, :, 1].cpu().double(), (slabs**2).sum(2), rtol=1e-5, atol=1e-5)
-    # consumer
-    wl = (w.double() * g.double()[None, :]).float()
-    hi, lo = ops.split_planes_host(wl)
-    colsum = (hi.double() + lo.double() / ops.SPLIT_LO_SCALE).sum(1).float()
-    b_ln = (b.double() + w.double() @ be.double()).float()
-    out = torch.empty(M, N, device=DEV)
-    ops.gemm_split(xs, ops.pack_split_rows_host(wl).to(DEV), M, N, C, out=out, bias=b_ln.to(DEV),
-                   ln_part=part, ln_colsum=colsum.to(DEV))
-    ref = F.layer_norm(xr.double(), (C, ), g.double(), be.double(), 1e-5) @ w.double().t() + b.double()
-    err = (out.cpu().double() - ref).abs()
-    assert (err <= 3e-5 + 3e-5 * ref.abs()).all(), err.max().item()
-
-
-def test_sampler_net_folded_layernorm_agrees_with_oracle():
-    from oracle import torch_ref as R
-    sd = synthetic.fill(synthetic.transformer_schema(18432, 1024, 18, 512, 4, 512, 18), seed=12)
-    P = weights.Params(DEV)
-    desc = weights.pack_transformer(P, sd, 'tf')
-    gen = torch.Generator().manual_seed(15)
-    idx = torch.randint(0, 18433, (2, 512), generator=gen)
-    seg = torch.randint(0, 1024, (2, 512), generator=gen)
-    tex = torch.randint(0, 18, (2, 512), generator=gen)
-    args = (idx.to(DEV), seg.to(DEV), tex.to(DEV))
-    a = engine.SamplerNet(P, desc, 8, 'tf', split=True, fold_ln=False).hidden(*args).clone().cpu()
-    b = engine.SamplerNet(P, desc, 8, 'tf', split=True, fold_ln=True).hidden(*args).clone().cpu()
-    with torch.no_grad():
-        ref = R.transformer_hidden(idx, seg, tex, sd)
-    ln = lambda t: F.layer_norm(t.view(2, 512, 512), (512, ), sd['ln_f.weight'], sd['ln_f.bias'], 1e-5)
-    ea, eb = (ln(a) - ref).abs().max().item(), (ln(b) - ref).abs().max().item()
-    assert ea < 1e-4 and eb < 1e-4, (ea, eb)
-    assert eb < 3 * ea + 2e-6, f'folded-LayerNorm path error {eb:.2e} vs separate LayerNorm {ea:.2e}'

@@ -32,7 +32,6 @@ class GemmArgs(ctypes.Structure):
         ('Hin', c_i32), ('Win', c_i32), ('Cin', c_i32), ('Hout', c_i32), ('Wout', c_i32),
         ('stride', c_i32), ('pad', c_i32), ('ups', c_i32), ('batch', c_i32),
         ('strideA', c_i64), ('strideB', c_i64), ('strideC', c_i64),
-        ('ln_stats_in', c_vp), ('ln_stats_out', c_vp), ('ln_eps', c_f32),
     ]
 
 
@@ -42,7 +41,6 @@ class GemmSplitArgs(ctypes.Structure):
         ('A', c_vp), ('B', c_vp), ('C', c_vp), ('C_split', c_vp), ('bias', c_vp), ('residual', c_vp),
         ('M', c_i32), ('N', c_i32), ('K', c_i32), ('ldc', c_i32), ('ldr', c_i32), ('epi_act', c_i32),
         ('Vt', c_vp), ('vt_col0', c_i32), ('vt_T', c_i32), ('vt_hd', c_i32),
-        ('ln_part', c_vp), ('ln_colsum', c_vp), ('ln_part_out', c_vp), ('ln_parts', c_i32), ('ln_eps', c_f32),
     ]
 
 
@@ -76,7 +74,6 @@ SIGNATURES = {
     't2h_groupnorm_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32]),
     't2h_groupnorm_tables_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                                 c_i32, c_i32, c_f32, c_vp, c_vp]),
-    't2h_row_stats_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     't2h_softmax_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_embed_sum4_f32': (ctypes.c_int, [c_vp] * 8 + [c_i32, c_i32, c_i32, c_vp]),
     't2h_mha_noncausal_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -260,18 +260,10 @@ __device__ long long* g_mha_timing = nullptr;  // debug builds only (tools/mha_s
 // matrix phase, then both in their softmax phase -- whereas independent halves drift
 // apart and run one wave's exp / split VALU work under the other's MFMAs.
 __device__ __forceinline__ void half_barrier(int* ctr, int target, int lane) {
-#ifdef T2H_MHA_BLOCK_BARRIER  // experiment: plain block barrier (tools/mha_split_ablate.py barrier)
-  __syncthreads();
-#else
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads / writes are done
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-#ifndef T2H_MHA_NOSLEEP
-    __builtin_amdgcn_s_sleep(1);
-#endif
-  }
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
-#endif
 }
 
 __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restrict__ qk, int ld_cols,
@@ -367,6 +359,9 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   // half stages exactly the tiles its own waves read (s_half == kh)
   int bar_n = 0;
   const long long tm1 = TM_NOW();
+  // the second-dispatched half of the workgroup loses every issue arbitration against its older SIMD
+  // partner (measured: its loop took 37k cycles against 26k): static priority evens the two out
+  if (kh == 1) __builtin_amdgcn_s_setprio(1);
   for (int it = 0; it < nit; ++it) {
     const long long ta = TM_NOW();
 #ifndef T2H_MDBG_NOSTAGE
@@ -378,52 +373,51 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
     const long long tb = TM_NOW();
     tm_stage += tb - ta;
 
-#ifdef T2H_MHA_IGLP
-    __builtin_amdgcn_iglp_opt(T2H_MHA_IGLP);  // experiment: LLVM's MFMA / exp interleaving strategies
-#endif
+    // ---- S^T = K Q^T for BOTH 32-key sub-tiles of the tile.  Issue order (l,h)0 (l,h)1 (h,h)0
+    // (h,l)0 (h,l)1 (h,h)1 per k16-step: consecutive matrix instructions never share an
+    // accumulator (a dependent v_mfma waits for its predecessor's last pass).
+    f32x16 st[2], st_lo[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {  // two 32-key sub-tiles
-      // ---- S^T = K Q^T
-      f32x16 st, st_lo;
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = st_lo[r] = 0.f;
-      const char* kp = Ks + (ks * 32 + l31) * SK_ROW + hh * 16;
+      for (int r = 0; r < 16; ++r) st[ks][r] = st_lo[ks][r] = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        f16x8 kf[2];
+    for (int kk = 0; kk < 4; ++kk) {
+      f16x8 kf[2][2];  // [sub-tile][plane]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
-          kf[pl] = *reinterpret_cast<const f16x8*>(kp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
+          kf[ks][pl] = *reinterpret_cast<const f16x8*>(Ks + (ks * 32 + l31) * SK_ROW + hh * 16 +
+                                                        (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
 #ifdef T2H_MDBG_NOMMA
-        asm volatile("" : "+v"(st), "+v"(st_lo) : "v"(kf[0]), "v"(kf[1]), "v"(qf[kk][0]), "v"(qf[kk][1]));
+      asm volatile("" : "+v"(st[0]), "+v"(st_lo[0]), "+v"(st[1]), "+v"(st_lo[1])
+                   : "v"(kf[0][0]), "v"(kf[0][1]), "v"(kf[1][0]), "v"(kf[1][1]), "v"(qf[kk][0]), "v"(qf[kk][1]));
 #else
-        st_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[0]], qf[kk][PB[0]], st_lo, 0, 0, 0);
-        st_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[1]], qf[kk][PB[1]], st_lo, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[2]], qf[kk][PB[2]], st, 0, 0, 0);
+      st_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][1], qf[kk][0], st_lo[0], 0, 0, 0);
+      st_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][1], qf[kk][0], st_lo[1], 0, 0, 0);
+      st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[kk][0], st[0], 0, 0, 0);
+      st_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[kk][1], st_lo[0], 0, 0, 0);
+      st_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][0], qf[kk][1], st_lo[1], 0, 0, 0);
+      st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][0], qf[kk][0], st[1], 0, 0, 0);
 #endif
-      }
-      // ---- online softmax over this lane's 16 keys + partner half's 16 keys
+    }
+    // ---- online softmax over the tile's 64 keys: this lane's 2 x 16 + the partner half's.  ONE
+    // rescale of the running state per tile, skipped (wave-uniformly) when no lane's maximum moved:
+    // alpha would be exp(0) = 1 exactly, so skipping changes no bit.
+    float mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = fmaf(st_lo[r], T2H_SPLIT_LO_INV, st[r]) * 0.125f;
-      float mx = st[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);  // first tile: 0
-      float psum = 0.f;
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-#ifdef T2H_MDBG_NOEXP
-        st[r] = st[r] - m_new;
-#else
-        st[r] = fast_exp(st[r] - m_new);
-#endif
-        psum += st[r];
+        st[ks][r] = fmaf(st_lo[ks][r], T2H_SPLIT_LO_INV, st[ks][r]) * 0.125f;
+        mx = fmaxf(mx, st[ks][r]);
       }
-      psum += __shfl_xor(psum, 32, 64);
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);  // first tile: 0
+      l_run *= alpha;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -431,33 +425,55 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
           o_acc[dt][r] *= alpha;
           o_lo[dt][r] *= alpha;
         }
-      // ---- O^T += V^T P^T ; k16-step j contracts keys {16j + 4h + (e&3) + 8(e>>2)} = registers 8j..8j+7
+      m_run = m_new;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // p = exp(s - m) in place, then O^T += V^T P^T; k16-step j contracts keys
+      // {16j + 4h + (e&3) + 8(e>>2)} = registers 8j..8j+7.  The exp / split VALU work of sub-tile 1
+      // is independent of sub-tile 0's matrix instructions and is scheduled into their shadow.
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+#ifdef T2H_MDBG_NOEXP
+        st[ks][r] = st[ks][r] - m_run;
+#else
+        st[ks][r] = fast_exp(st[ks][r] - m_run);
+#endif
+        psum += st[ks][r];
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f16x8 pf[2];
 #ifdef T2H_MDBG_NOSPLIT
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[0][e] = pf[1][e] = (_Float16)st[8 * j + e];
+        for (int e = 0; e < 8; ++e) pf[0][e] = pf[1][e] = (_Float16)st[ks][8 * j + e];
 #else
-        if (j == 0) split8<0>(st, pf[0], pf[1]);
-        else split8<1>(st, pf[0], pf[1]);
+        if (j == 0) split8<0>(st[ks], pf[0], pf[1]);
+        else split8<1>(st[ks], pf[0], pf[1]);
 #endif
+        f16x8 vf[2][2];  // [d half][plane]
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          f16x8 vf[2];
-          const char* vp = Vs + (dt * 32 + l31) * SV_ROW + (ks * 32 + 16 * j + 8 * hh) * 2;
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) vf[pl] = *reinterpret_cast<const f16x8*>(vp + pl * HD * SV_ROW);
+          for (int pl = 0; pl < 2; ++pl)
+            vf[dt][pl] = *reinterpret_cast<const f16x8*>(Vs + (dt * 32 + l31) * SV_ROW + pl * HD * SV_ROW +
+                                                          (ks * 32 + 16 * j + 8 * hh) * 2);
 #ifdef T2H_MDBG_NOMMA
-          asm volatile("" : "+v"(o_acc[dt]), "+v"(o_lo[dt]) : "v"(vf[0]), "v"(vf[1]), "v"(pf[0]), "v"(pf[1]));
+        asm volatile("" : "+v"(o_acc[0]), "+v"(o_lo[0]), "+v"(o_acc[1]), "+v"(o_lo[1])
+                     : "v"(vf[0][0]), "v"(vf[0][1]), "v"(vf[1][0]), "v"(vf[1][1]), "v"(pf[0]), "v"(pf[1]));
 #else
-          o_lo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[PA[0]], pf[PB[0]], o_lo[dt], 0, 0, 0);
-          o_lo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[PA[1]], pf[PB[1]], o_lo[dt], 0, 0, 0);
-          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[PA[2]], pf[PB[2]], o_acc[dt], 0, 0, 0);
+        o_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], pf[0], o_lo[0], 0, 0, 0);
+        o_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], pf[0], o_lo[1], 0, 0, 0);
+        o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pf[0], o_acc[0], 0, 0, 0);
+        o_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pf[1], o_lo[0], 0, 0, 0);
+        o_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[1], o_lo[1], 0, 0, 0);
+        o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[0], o_acc[1], 0, 0, 0);
 #endif
-        }
       }
     }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run += psum;
     tm_comp += TM_NOW() - tb;
   }
 

@@ -312,56 +312,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
       const bool ok = (b_ok >> i) & 1u;
       b_src[i] = Bg + (int64_t)(ok ? n0 + row0 + RPP * i : 0) * p.ldb + col4 * 4;
     }
-    // Fused LayerNorm prologue: a' = a * s_r + t_r with s_r = rstd(row), t_r =
-    // -mean(row) * rstd(row); the statistics come as per-row partial (sum, sumsq)
-    // slabs written by the producer's epilogue (summed here in a fixed order ->
-    // deterministic).  gamma / beta are folded into W / bias by the host.
-    float ln_s[A_F4], ln_t[A_F4];
-    const bool has_ln = p.ln_stats_in != nullptr;
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-      ln_s[i] = 1.f;
-      ln_t[i] = 0.f;
-    }
-    if (has_ln) {
-      // one thread per tile row reduces that row's slabs (wide loads, fixed order),
-      // the (s, t) pairs are handed to the staging threads through LDS
-      __shared__ float ln_lds[2 * BM];
-      if (tid < BM) {
-        const int m = m0 + tid;
-        float s = 1.f, t = 0.f;
-        if (m < p.M) {
-          const int ln_slabs = p.K >> 5;  // (sum, sumsq) pairs: 2 pairs per float4
-          const f32x4* sp = reinterpret_cast<const f32x4*>(p.ln_stats_in + (int64_t)m * ln_slabs * 2);
-          float su = 0.f, sq = 0.f;
-          for (int k = 0; k < ln_slabs / 2; ++k) {
-            const f32x4 v = sp[k];
-            su += v[0];
-            sq += v[1];
-            su += v[2];
-            sq += v[3];
-          }
-          const float inv_n = 1.0f / (float)p.K;
-          const float mean = su * inv_n;
-          const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
-          s = 1.0f / sqrtf(var + p.ln_eps);
-          t = -mean * s;
-        }
-        ln_lds[2 * tid] = s;
-        ln_lds[2 * tid + 1] = t;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < A_F4; ++i) {
-        ln_s[i] = ln_lds[2 * (row0 + RPP * i)];
-        ln_t[i] = ln_lds[2 * (row0 + RPP * i) + 1];
-      }
-    }
     auto put_a = [&](int i, const f32x4& r, int buf) {
       f32x4 v = r;
       const bool ok = (a_ok >> i) & 1u;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = ok ? (has_ln ? fmaf(v[e], ln_s[i], ln_t[i]) : v[e]) : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
       *reinterpret_cast<f32x4*>(As + buf * BM * LDS_LD + (row0 + RPP * i) * LDS_LD + col4 * 4) = v;
     };
     auto put_b = [&](int i, const f32x4& r, int buf) {
@@ -542,51 +497,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
         else if (p.epi_act == 2) v = fmaxf(v, 0.f);
         if (!p.res_pre) v += rv;
         Cg[(int64_t)row * p.ldc + col] = v;
-        acc[ti][tj][r] = v;  // final value, reused by the row-statistics epilogue
-      }
-    }
-  }
-  // ---- optional LayerNorm statistics of the OUTPUT rows for the next GEMM's fused
-  // prologue: per row and 32-column slab the (sum, sum of squares) of the final
-  // values, reduced over the 32 lanes of a wave half in a fixed butterfly order
-  // and written by exactly one lane (deterministic, no atomics).  N % 32 == 0.
-  if (p.ln_stats_out) {
-    const int slabs = p.N >> 5;
-#pragma unroll
-    for (int ti = 0; ti < TM; ++ti) {
-#pragma unroll
-      for (int tj = 0; tj < TN; ++tj) {
-        const int slab = (n0 + wn0 + tj * 32) >> 5;
-        // Reduce-scatter butterfly over the 32 lanes of a wave half: 16 row values
-        // per lane -> after offsets 16, 8, 4, 2 every lane keeps ONE row (register
-        // index r = bits of lane&30 >> 1) summed over 16 lanes, offset 1 completes
-        // it: 16 + 16 exchanges per quantity pair instead of 16 x 5.
-        float su[16], sq[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          su[r] = acc[ti][tj][r];
-          sq[r] = su[r] * su[r];
-        }
-#pragma unroll
-        for (int o = 16, n = 8; o >= 2; o >>= 1, n >>= 1) {
-          const bool up = (l31 & o) != 0;  // upper lanes keep the upper half of the list
-#pragma unroll
-          for (int i = 0; i < n; ++i) {
-            const float ks = up ? su[i + n] : su[i], ss = up ? su[i] : su[i + n];
-            const float kq = up ? sq[i + n] : sq[i], sq_s = up ? sq[i] : sq[i + n];
-            su[i] = ks + __shfl_xor(ss, o, 64);
-            sq[i] = kq + __shfl_xor(sq_s, o, 64);
-          }
-        }
-        const float tsu = su[0] + __shfl_xor(su[0], 1, 64);
-        const float tsq = sq[0] + __shfl_xor(sq[0], 1, 64);
-        const int r = (l31 >> 1) & 15;  // bit3 = lane&16, bit2 = lane&8, bit1 = lane&4, bit0 = lane&2
-        const int row = m0 + wm0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if ((l31 & 1) == 0 && row < p.M && slab < slabs) {
-          float* d = p.ln_stats_out + ((int64_t)row * slabs + slab) * 2;
-          d[0] = tsu;
-          d[1] = tsq;
-        }
       }
     }
   }
@@ -705,11 +615,6 @@ extern "C" int t2h_gemm_f32(const t2h_gemm_args* args, void* stream) {
                 "t2h_gemm_f32: prologue tables must be 16-byte aligned rows");
     if (a.a_mode == 0) T2H_REQUIRE(a.pro_rows > 0, "t2h_gemm_f32: pro_rows must be > 0");
   }
-  if (a.ln_stats_in)
-    T2H_REQUIRE(a.a_mode == 0 && !a.b_trans && !a.pro_scale && a.K % 64 == 0 &&
-                    t2h_aligned16(a.ln_stats_in),
-                "t2h_gemm_f32: ln_stats_in needs a plain GEMM without prologue tables, K %% 64 == 0");
-  if (a.ln_stats_out) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_f32: ln_stats_out needs N %% 32 == 0");
   if (a.a_mode == 1) {
     T2H_REQUIRE(!a.b_trans, "t2h_gemm_f32: conv with b_trans unsupported");
     T2H_REQUIRE(a.Cin % 32 == 0 && a.K == 9 * a.Cin, "t2h_gemm_f32: conv needs Cin %% 32 == 0 and K == 9*Cin (Cin=%d K=%d)", a.Cin, a.K);

@@ -119,7 +119,7 @@ __device__ long long* g1_timing = nullptr;  // debug builds only (tools/gemm_pha
 // g takes tiles 2s + g); the partial sums meet in LDS in the epilogue, group 0 first, so
 // the result is deterministic.  It gives a tile that only fills the chip at one block
 // per CU (N = 512 at M = 4096) two waves per SIMD without shrinking the wave tile.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, bool GLDS = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p, int* const ovf) {
   constexpr int NT = 64 * WARPS_M * WARPS_N;  // threads per K group
   constexpr int NWG = WARPS_M * WARPS_N;      // waves per K group
@@ -138,12 +138,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   constexpr int OT_LD = WM + 4;                  // transposed staging (value planes): floats per column
   constexpr int OW = WM * O_LD > WN * OT_LD ? WM * O_LD : WN * OT_LD;  // staging floats per wave
   constexpr int EPI_B = OW * 4 * NWG * KS;
-  constexpr int ROWS_T = BM + BN;                // rows of a tile image
-  constexpr int TILE_IMG_B = ROWS_T * SP_TILE_B; // LDS-DMA variant: unpadded image, 3 buffers
-  constexpr int MAIN_B = GLDS ? 3 * TILE_IMG_B : 2 * BUF_B * KS;
+  constexpr int MAIN_B = 2 * BUF_B * KS;
   constexpr int SMEM_B = MAIN_B > EPI_B ? MAIN_B : EPI_B;
 
-  __shared__ __attribute__((aligned(16))) char smem[SMEM_B + BM * 8];  // + (mean, rstd) of the BM rows
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
 
   G1_MARK(0);
   const int kg = KS == 1 ? 0 : (int)threadIdx.x / NT;  // K group
@@ -168,20 +166,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   const int64_t row_b = (int64_t)nk * (SP_TILE_B * KS);  // bytes per split row
   constexpr int K_STEP_B = SP_TILE_B * KS;               // bytes between a group's K tiles
 
-  // folded LayerNorm: the row partials are summed (fixed order) up front, under the first
-  // tile loads, and turned into (mean, rstd) after the main loop
-  const bool ln_in = p.ln_part != nullptr;
-  float ln_su = 0.f, ln_sq = 0.f;
-  if (ln_in && (int)threadIdx.x < BM) {
-    const float2* pp =
-        reinterpret_cast<const float2*>(p.ln_part) + (int64_t)min(m0 + (int)threadIdx.x, p.M - 1) * p.ln_parts;
-    for (int i = 0; i < p.ln_parts; ++i) {
-      const float2 v = pp[i];
-      ln_su += v.x;
-      ln_sq += v.y;
-    }
-  }
-
   f32x16 acc[2][TM][TN];  // [0] ah*bh, [1] the 2^-11 terms ah*bl + al*bh
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -192,7 +176,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
-  if constexpr (!GLDS) {
   // ---- per-thread staging slots (fixed for the whole kernel).  Rows beyond M / N are
   // loaded from a clamped (valid) address and NOT masked: an output element depends only
   // on its own A row and B row, and rows / columns beyond the problem are never stored.
@@ -310,107 +293,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   for (int S = 0; S < 2; ++S)
 #pragma unroll
     for (int i = 0; i < L; ++i) wait_vmcnt16<0>(rg[S][i]);
-  } else {
-    // ---- LDS-DMA main loop (GLDS): global_load_lds_dwordx4 writes the K tiles straight into
-    // LDS -- no staging registers, no ds_write pass, ONE counted wait + ONE barrier per K step.
-    // A DMA instruction fills 1 KiB = 8 rows x 128 B lane-linearly, so the image is unpadded;
-    // bank conflicts of the 16-byte fragment reads are avoided by an XOR swizzle instead:
-    // logical piece c of row r lives at piece c ^ ((r >> 1) & 7), applied on the SOURCE
-    // address of the DMA and on the fragment read address.  Three tile buffers: while tile kt
-    // is multiplied, tile kt+1 is landing and tile kt+2 is requested into the buffer that
-    // tile kt-1 occupied (free since the barrier that ended step kt-1).
-    static_assert(KS == 1 && NT % 64 == 0 && (ROWS_T * 8) % NT == 0, "LDS-DMA variant: tile / thread shape");
-    constexpr int NL = ROWS_T * 8 / NT;          // DMA instructions per wave and K tile
-    const unsigned lds0 = (unsigned)(uintptr_t)smem;
-    const char* gsrc[NL];
-    unsigned gdst[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int g = wave + (NT / 64) * i;        // 8-row group of the tile image
-      const int r = g * 8 + (lane >> 3), pc = (lane & 7) ^ ((r >> 1) & 7);
-      const bool isA = r < BM;
-      const int grow = isA ? min(m0 + r, p.M - 1) : min(n0 + r - BM, p.N - 1);
-      gsrc[i] = reinterpret_cast<const char*>(isA ? p.A : p.B) + (int64_t)grow * row_b + pc * 16;
-      gdst[i] = lds0 + g * 1024;
-    }
-    auto dma = [&](int kt, int buf) {
-      const int64_t k0 = (int64_t)min(kt, last) * SP_TILE_B;
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        unsigned keep;
-        const char* src_i = gsrc[i] + k0;
-        const unsigned dst_i = __builtin_amdgcn_readfirstlane(gdst[i] + buf * TILE_IMG_B);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src_i), "s"(dst_i)
-                     : "memory");
-      }
-    };
-    constexpr int PA[3] = {1, 0, 0};
-    constexpr int PB[3] = {0, 1, 0};
-    constexpr int PC[3] = {1, 1, 0};
-    // fragment read offsets inside a tile image: row * 128 + ((plane * 4 + u * 2 + hh) ^ swizzle) * 16
-    const int swz = (l31 >> 1) & 7;
-    int offA[4], offB[4];
-#pragma unroll
-    for (int c2 = 0; c2 < 4; ++c2) {
-      const int pcs = ((c2 * 2 + hh) ^ swz) * 16;
-      offA[c2] = (wm0 + l31) * 128 + pcs;
-      offB[c2] = (BM + wn0 + l31) * 128 + pcs;
-    }
-    auto compute = [&](int buf) {
-      const char* img = smem + buf * TILE_IMG_B;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f16x8 af[TM][2], bfr[TN][2];
-#pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            af[ti][pl] = *reinterpret_cast<const f16x8*>(img + ti * 32 * 128 + offA[pl * 2 + u]);
-#pragma unroll
-        for (int tj = 0; tj < TN; ++tj)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            bfr[tj][pl] = *reinterpret_cast<const f16x8*>(img + tj * 32 * 128 + offB[pl * 2 + u]);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int ti = 0; ti < TM; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TN; ++tj)
-              acc[PC[t]][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ti][PA[t]], bfr[tj][PB[t]],
-                                                                           acc[PC[t]][ti][tj], 0, 0, 0);
-      }
-    };
-    // sched_barrier(0): the machine scheduler must not move the fragment reads of the next
-    // tile above the wait + barrier that publish it (it does, otherwise)
-    dma(0, 0);
-    dma(1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");  // tile 0 landed (tile 1 may be in flight)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    auto kstep = [&](int kt, int buf) {  // buf = kt % 3
-      dma(kt + 2, buf == 0 ? 2 : buf - 1);         // (kt + 2) % 3
-      compute(buf);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");  // tile kt+1 landed
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 3) {
-      kstep(kt, 0);
-      kstep(kt + 1, 1);
-      kstep(kt + 2, 2);
-    }
-    if (kt < nk) kstep(kt, 0);
-    if (kt + 1 < nk) kstep(kt + 1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead requests too, before
-    __syncthreads();                                  // the tile buffers are reused by the epilogue
-  }
-
   G1_MARK(2);
   // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (r&3) +
   // 8*(r>>2) + 4*(lane>>5)) are transposed through the (now idle) LDS so that every
@@ -419,41 +301,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   // 2-byte ones.
   float* const Ot = reinterpret_cast<float*>(smem) + wave * OW;  // group 0's staged wave tile
   float* const Og = Ot + kg * (NWG * OW);                        // this group's
-  // Folded LayerNorm (ln_part != NULL): A holds the raw rows x, B the weights scaled by
-  // gamma; with s_j = sum_k B[j][k] the Linear of LN(x) is rstd_i (acc_ij - mean_i s_j) + b'_j.
-  // mean / rstd of this block's rows come from the producer's per-32-column partial
-  // (sum, sum of squares), summed here in a fixed order.
-  float2* const rowstat = reinterpret_cast<float2*>(smem + SMEM_B);
-  if (ln_in) {
-    if ((int)threadIdx.x < BM) {
-      const float inv_c = 1.0f / (float)p.K;
-      const float mean = ln_su * inv_c;
-      const float var = fmaxf(ln_sq * inv_c - mean * mean, 0.f);
-      rowstat[threadIdx.x] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
-    }
-    __syncthreads();
-  }
-  // value of accumulator register r of MFMA tile (ti, tj) as it is staged: both K-split
-  // partial accumulators, the folded-LayerNorm correction (group 0 only), the bias
-  // (the 16 rows of a lane's registers in MFMA row-tile ti are 4 runs of 4 consecutive
-  // rows: their (mean, rstd) are fetched as 8 16-byte LDS reads per ti, not 16 x TN small ones)
-  float2 rs[16];
-  auto load_rowstats = [&](int ti) {
-    if (!ln_in) return;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4* q = reinterpret_cast<const f32x4*>(rowstat + wm0 + ti * 32 + 8 * g4 + 4 * hh);
-      const f32x4 lo = q[0], hi2 = q[1];
-      rs[4 * g4 + 0] = make_float2(lo[0], lo[1]);
-      rs[4 * g4 + 1] = make_float2(lo[2], lo[3]);
-      rs[4 * g4 + 2] = make_float2(hi2[0], hi2[1]);
-      rs[4 * g4 + 3] = make_float2(hi2[2], hi2[3]);
-    }
-  };
-  auto fin = [&](int ti, int tj, int r, float bv, float sj) {
-    float v = fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]);
-    if (ln_in) v = rs[r].y * (v - (kg == 0 ? rs[r].x * sj : 0.f));
-    return v + bv;
+  // value of accumulator register r of MFMA tile (ti, tj) as it is staged: both partial
+  // accumulators folded together, plus the bias (K group 0 only)
+  auto fin = [&](int ti, int tj, int r, float bv) {
+    return fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]) + bv;
   };
   if (p.Vt != nullptr && n0 >= p.vt_col0) {
     // Value heads of the q|k|v projection -> transposed planes Vt[B][H][2][hd][T].  The wave
@@ -464,17 +315,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     // so the store is one 16-byte piece per plane and contiguous across lanes.
 #pragma unroll
     for (int ti = 0; ti < TM; ++ti) {
-      load_rowstats(ti);
 #pragma unroll
       for (int tj = 0; tj < TN; ++tj) {
         const int col = n0 + wn0 + tj * 32 + l31;
         const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
-        const float sj = (ln_in && col < p.N) ? p.ln_colsum[col] : 0.f;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           f32x4 w4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) w4[e] = fin(ti, tj, 4 * g4 + e, bv, sj);
+          for (int e = 0; e < 4; ++e) w4[e] = fin(ti, tj, 4 * g4 + e, bv);
           *reinterpret_cast<f32x4*>(Og + (tj * 32 + l31) * OT_LD + ti * 32 + 8 * g4 + 4 * hh) = w4;
         }
       }
@@ -520,15 +369,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   }
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti) {
-    load_rowstats(ti);
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) {
       const int col = n0 + wn0 + tj * 32 + l31;
       const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
-      const float sj = (ln_in && col < p.N) ? p.ln_colsum[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = fin(ti, tj, r, bv, sj);
+        Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = fin(ti, tj, r, bv);
     }
   }
   __syncthreads();
@@ -541,7 +388,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     const int rl = c / CPR, c8 = (c - rl * CPR) * 8;
     const int row = m0 + wm0 + rl, col = n0 + wn0 + c8;
     const bool valid = row < p.M && col < p.N;
-    if (!valid && !p.ln_part_out) continue;
+    if (!valid) continue;
     f32x4 va = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8);
     f32x4 vb = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8 + 4);
     if (KS == 2) {
@@ -558,29 +405,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
         vb[e] = fmaxf(vb[e], 0.f);
       }
     }
-    if (p.residual && valid) {
+    if (p.residual) {
       va += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
       vb += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col + 4);
-    }
-    if (p.ln_part_out) {
-      // per-row (sum, sum of squares) of this wave tile's 32 columns for the consumer's
-      // folded LayerNorm: the CPR lanes that hold a row are adjacent
-      float su = 0.f, sq = 0.f;
-      if (valid) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          su += va[e] + vb[e];
-          sq = fmaf(va[e], va[e], fmaf(vb[e], vb[e], sq));
-        }
-      }
-#pragma unroll
-      for (int o = 1; o < CPR; o <<= 1) {
-        su += __shfl_xor(su, o, 64);
-        sq += __shfl_xor(sq, o, 64);
-      }
-      if (valid && c8 == 0)
-        reinterpret_cast<float2*>(p.ln_part_out)[(int64_t)row * (p.N / WN) + (n0 + wn0) / WN] = make_float2(su, sq);
-      if (!valid) continue;
     }
     if (p.C) {
       *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = va;
@@ -606,18 +433,16 @@ __global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t
   t2h_store_split4(out, row, C, c0, *reinterpret_cast<const f32x4*>(x + row * ldx + c0), ovf);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1, bool GLDS = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1>
 int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE(a.K % (32 * KS) == 0, "t2h_gemm_split_f32: this tile config needs K %% %d == 0", 32 * KS);
-  T2H_REQUIRE(!a.ln_part_out || BN / WARPS_N == 32,
-              "t2h_gemm_split_f32: LayerNorm partials need a tile config with 32-column wave tiles");
   if (a.Vt)
     T2H_REQUIRE(a.vt_col0 % BN == 0, "t2h_gemm_split_f32: vt_col0=%d must be a multiple of the %d-column tile",
                 a.vt_col0, BN);
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
   int* ovf = t2h_split_overflow_flag_ptr();
   T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, GLDS>), grid,
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS>), grid,
                      dim3(64 * WARPS_M * WARPS_N * KS), 0, s, a, ovf);
   T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
   return T2H_OK;
@@ -650,10 +475,6 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
                   (!a.residual || (a.ldr % 4 == 0 && t2h_aligned16(a.residual))),
               "t2h_gemm_split_f32: N must be a multiple of 8, ldc / ldr of 4, C / residual 16-byte aligned");
   if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
-  if (a.ln_part)
-    T2H_REQUIRE(a.ln_colsum && a.ln_parts > 0 && a.ln_eps > 0.f, "t2h_gemm_split_f32: incomplete folded-LayerNorm input");
-  if (a.ln_part_out)
-    T2H_REQUIRE(a.N % 32 == 0 && a.Vt == nullptr, "t2h_gemm_split_f32: LayerNorm partials need N %% 32 == 0, no Vt");
   if (a.Vt)
     T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 128 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&
                     a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,
@@ -672,7 +493,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     if (a.M <= 64) cfg = 2;
     else if (tiles128 >= 1024) cfg = 1;
     else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
-    else if (a.N % 128 == 0 && a.M % 256 == 0 && tiles128 / 2 >= 192 && tiles128 / 2 <= 256 && !a.ln_part_out)
+    else if (a.N % 128 == 0 && a.M % 256 == 0 && tiles128 / 2 >= 192 && tiles128 / 2 <= 256)
       cfg = 4;  // qkv / fc1 at M = 4096: 192 / 256 tiles of 256x128, at most one per CU
     else cfg = 0;
   }
@@ -683,7 +504,6 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     case 4: return launch_split<256, 128, 4, 2>(a, s);  // 8 waves, wave tile 64x64
     case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
     case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
-    case 7: return launch_split<128, 64, 2, 2, 1, true>(a, s);  // cfg 0 with the LDS-DMA main loop
     default: return launch_split<128, 64, 2, 2>(a, s);  // 4 waves, wave tile 64x32
   }
 }

@@ -27,36 +27,6 @@ __global__ void embed_sum4_kernel(const int64_t* __restrict__ idx, const int64_t
   }
 }
 
-// Per-row, per-32-column-slab (sum, sum of squares) of x[rows, C]: the LayerNorm
-// statistics layout consumed by the GEMM's fused prologue (t2h_gemm_args.ln_stats_in)
-// and produced by GEMM epilogues (ln_stats_out); this kernel seeds it for a tensor
-// that did not come out of a GEMM (the embedding sum).  One wave per row.
-template <int VPL>  // C = 256 * VPL
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x,
-                                                        float* __restrict__ stats, int rows) {
-  constexpr int C = 256 * VPL;
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* xr = x + (int64_t)row * C;
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
-    float su = (v[0] + v[1]) + (v[2] + v[3]);
-    float sq = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {  // 8 lanes x 4 columns = one 32-column slab
-      su += __shfl_xor(su, o, 64);
-      sq += __shfl_xor(sq, o, 64);
-    }
-    if ((lane & 7) == 0) {
-      float* d = stats + ((int64_t)row * (C / 32) + i * 8 + (lane >> 3)) * 2;
-      d[0] = su;
-      d[1] = sq;
-    }
-  }
-}
-
 // changes = rand < 1/t ; changes &= ~unmasked ; unmasked |= changes
 // (models/sample_model.py:286-292).  `1 / t.float()` is an fp32 reciprocal.
 // With changed_rows: the changed tokens are also appended to that list (in no particular
@@ -333,22 +303,6 @@ extern "C" int t2h_embed_sum4_f32(const int64_t* idx, const int64_t* segm, const
   hipLaunchKernelGGL(embed_sum4_kernel, dim3(B * T), dim3(128), 0, static_cast<hipStream_t>(stream),
                      idx, segm, tex, tok_emb, pos_emb, segm_emb, tex_emb, x, T, C);
   T2H_CHECK_LAUNCH("t2h_embed_sum4_f32");
-  return T2H_OK;
-}
-
-extern "C" int t2h_row_stats_f32(const float* x, float* stats, int32_t rows, int32_t C, void* stream) {
-  T2H_REQUIRE(x && stats, "t2h_row_stats_f32: NULL pointer");
-  T2H_REQUIRE(rows > 0 && t2h_aligned16(x), "t2h_row_stats_f32: bad arguments");
-  dim3 grid((rows + 3) / 4), block(256);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (C == 512) hipLaunchKernelGGL(row_stats_kernel<2>, grid, block, 0, s, x, stats, rows);
-  else if (C == 256) hipLaunchKernelGGL(row_stats_kernel<1>, grid, block, 0, s, x, stats, rows);
-  else if (C == 1024) hipLaunchKernelGGL(row_stats_kernel<4>, grid, block, 0, s, x, stats, rows);
-  else {
-    t2h_set_error("t2h_row_stats_f32: C=%d unsupported (256/512/1024)", C);
-    return T2H_ERR_UNSUPPORTED;
-  }
-  T2H_CHECK_LAUNCH("t2h_row_stats_f32");
   return T2H_OK;
 }
 

@@ -129,21 +129,9 @@ class SamplerNet:
     tail kernel.  24 x [LN, QKV GEMM, flash MHA, proj GEMM(+res), LN, fc1
     GEMM(+GELU), fc2 GEMM(+res)]."""
 
-    def __init__(self, P, desc, n_head, name='tf', fuse_ln=False, split=False, split_mha=True, n_streams=1,
-                 fold_ln=False):
+    def __init__(self, P, desc, n_head, name='tf', split=False, split_mha=True, n_streams=1):
         self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
         self.split = split
-        # fold_ln (with split + split_mha; parity-tested, but MEASURED 1 % SLOWER at B=8 on
-        # MI355X -- 1020 vs 1010 ms per batch on the same box: the extra split-row write and
-        # statistics in the producers' epilogues (+2-3 us per launch) and the per-row
-        # correction in the consumers' (+3-4 us, tools/fold_ln_probe.py) cost what the two
-        # 6-7 us LayerNorm launches per layer save -- so it is off by default): no LayerNorm
-        # launches after the first one.  The
-        # residual GEMMs (proj, fc2) also emit the new x as split rows plus per-row partial
-        # (sum, sum of squares); the next Linear (qkv, fc1) multiplies the RAW rows by the
-        # gamma-scaled weights and applies mean / rstd in its epilogue
-        # (t2h_gemm_split_args.ln_part).
-        self.fold_ln = fold_ln
         # n_streams > 1 (split path): the batch is cut into that many independent slices
         # whose 24-layer kernel chains run on separate HIP streams, so one slice's launch
         # latency / first-tile fill / epilogue tail overlaps the other's main loops
@@ -152,12 +140,6 @@ class SamplerNet:
         # split_mha (with split): attention on the fp16 matrix cores too -- the q|k|v
         # projection writes q, k as split rows and v as transposed planes, no fp32 qkv
         self.split_mha = split_mha
-        # fuse_ln: LayerNorm folded into the GEMM operand staging + statistics from
-        # the producer's epilogue.  Parity-tested, but MEASURED SLOWER at B=8 on
-        # MI355X (2042 vs 1961 ms per batch: the statistics prologue/epilogue cost
-        # the K=512 GEMMs more than the 48 LayerNorm launches per step save), so
-        # the separate LayerNorm kernel stays the default.
-        self.fuse_ln = fuse_ln
         self._buf = {}
 
     def _buffers(self, M, C, dev):
@@ -165,12 +147,9 @@ class SamplerNet:
         if key not in self._buf:
             e = lambda n: torch.empty((M, n), device=dev, dtype=torch.float32)
             self._buf = {key: dict(x=e(C), h=e(C), qkv=e(3 * C), y=e(C), u=e(4 * C),
-                                   stats=torch.empty((M, C // 32, 2), device=dev, dtype=torch.float32),
                                    h_split=ops.split_rows_empty(M, C, dev), y_split=ops.split_rows_empty(M, C, dev),
                                    u_split=ops.split_rows_empty(M, 4 * C, dev),
                                    qk_split=ops.split_rows_empty(M, 3 * C, dev),
-                                   x_split=ops.split_rows_empty(M, C, dev),
-                                   ln_part=torch.empty((M, C // 32, 2), device=dev, dtype=torch.float32),
                                    vt=ops.vt_empty(M // 512 if M % 512 == 0 else 1, self.n_head, 512, dev))}
         return self._buf[key]
 
@@ -198,33 +177,7 @@ class SamplerNet:
             Bs = B // ns
             sl = [(j * Bs * T, (j + 1) * Bs * T, j * Bs, (j + 1) * Bs) for j in range(ns)]
 
-            fold = self.fold_ln and self.split_mha
-            xsp, lnp = buf['x_split'], buf['ln_part']
-
-            def layer_folded(i, lo, hi, b0, b1):
-                p = f'{nm}.{i}'
-                m, xs = hi - lo, x[lo:hi]
-                hd = C // self.n_head
-                if i == 0:  # x comes from the embedding kernel: one real LayerNorm
-                    ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])
-                    ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out_split=qks[lo:hi],
-                                   bias=P[f'{p}.qkv.b'], vt=vt[b0:b1], vt_col0=2 * C, vt_T=T, vt_hd=hd)
-                else:
-                    ops.gemm_split(xsp[lo:hi], P[f'{p}.qkv.w_ln_split'], m, 3 * C, C, out_split=qks[lo:hi],
-                                   bias=P[f'{p}.qkv.b_ln'], vt=vt[b0:b1], vt_col0=2 * C, vt_T=T, vt_hd=hd,
-                                   ln_part=lnp[lo:hi], ln_colsum=P[f'{p}.qkv.colsum'])
-                ops.mha_split(qks[lo:hi], 3 * C, vt[b0:b1], b1 - b0, T, self.n_head, out_split=ys[lo:hi])
-                ops.gemm_split(ys[lo:hi], P[f'{p}.proj.w_split'], m, C, C, out=xs, out_split=xsp[lo:hi],
-                               bias=P[f'{p}.proj.b'], residual=xs, ln_part_out=lnp[lo:hi])
-                ops.gemm_split(xsp[lo:hi], P[f'{p}.fc1.w_ln_split'], m, 4 * C, C, out_split=us[lo:hi],
-                               bias=P[f'{p}.fc1.b_ln'], act=ACT_GELU, ln_part=lnp[lo:hi],
-                               ln_colsum=P[f'{p}.fc1.colsum'])
-                ops.gemm_split(us[lo:hi], P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xs, out_split=xsp[lo:hi],
-                               bias=P[f'{p}.fc2.b'], residual=xs, ln_part_out=lnp[lo:hi])
-
             def layer(i, lo, hi, b0, b1):
-                if fold:
-                    return layer_folded(i, lo, hi, b0, b1)
                 p = f'{nm}.{i}'
                 m, xs = hi - lo, x[lo:hi]
                 ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])
@@ -260,21 +213,6 @@ class SamplerNet:
                         layer(i, *sl[j])
             for st in self._streams:
                 main.wait_stream(st)
-            return x
-        if self.fuse_ln:
-            # LayerNorm never materialises: the residual GEMMs (proj, fc2) emit the
-            # row statistics of the new x in their epilogue, the next GEMM (QKV, fc1)
-            # normalises its A operand while staging it (gamma/beta folded into W/b).
-            st = buf['stats']
-            ops.row_stats(x, out=st)
-            for i in range(self.desc['n_layers']):
-                p = f'{nm}.{i}'
-                ops.gemm(x, P[f'{p}.qkv.w_ln'], out=qkv, bias=P[f'{p}.qkv.b_ln'], ln_stats_in=st)
-                ops.mha_noncausal(qkv, B, T, self.n_head, out=y)
-                ops.gemm(y, P[f'{p}.proj.w'], out=x, bias=P[f'{p}.proj.b'], residual=x, ln_stats_out=st)
-                ops.gemm(x, P[f'{p}.fc1.w_ln'], out=u, bias=P[f'{p}.fc1.b_ln'], act=ACT_GELU,
-                         ln_stats_in=st)
-                ops.gemm(u, P[f'{p}.fc2.w'], out=x, bias=P[f'{p}.fc2.b'], residual=x, ln_stats_out=st)
             return x
         for i in range(self.desc['n_layers']):
             p = f'{nm}.{i}'

@@ -69,9 +69,8 @@ class BaseSampleModel():
         split = os.environ.get('T2H_SPLIT_GEMM', '1') != '0'
         split_mha = os.environ.get('T2H_SPLIT_MHA', '1') != '0'
         n_streams = int(os.environ.get('T2H_SAMPLER_STREAMS', '1'))
-        fold_ln = os.environ.get('T2H_FOLD_LN', '0') == '1'
         self.sampler_fn = engine.SamplerNet(P, d_tf, self.opt['bert_n_head'], 'tf', split=split,
-                                            split_mha=split_mha, n_streams=n_streams, fold_ln=fold_ln)
+                                            split_mha=split_mha, n_streams=n_streams)
 
     # ------------------------------------------------------------ helpers
     def _texture_tokens(self, texture_mask):

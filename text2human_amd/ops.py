@@ -98,7 +98,7 @@ def _launch_gemm(g, what):
 
 
 def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=None,
-         b_trans=False, ln_stats_in=None, ln_stats_out=None, ln_eps=1e-5):
+         b_trans=False):
     """out[M,N] = act(alpha * pro(a)[M,K] @ w[N,K]^T + bias) + residual.
 
     a, w, out, residual: 2-D views with unit inner stride (row stride free).
@@ -124,14 +124,6 @@ def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_rows, g.pro_ld, g.pro_act = rows, sc.shape[1], pact
     g.batch = 1
-    if ln_stats_in is not None:
-        _chk_f32(ln_stats_in)
-        assert ln_stats_in.is_contiguous() and ln_stats_in.numel() == M * (K // 32) * 2
-        g.ln_stats_in, g.ln_eps = ln_stats_in.data_ptr(), ln_eps
-    if ln_stats_out is not None:
-        _chk_f32(ln_stats_out)
-        assert ln_stats_out.is_contiguous() and ln_stats_out.numel() == M * (N // 32) * 2
-        g.ln_stats_out = ln_stats_out.data_ptr()
     _launch_gemm(g, 't2h_gemm_f32')
     return out
 
@@ -248,7 +240,7 @@ def pack_split_rows_host(w):
 
 
 def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE,
-               vt=None, vt_col0=0, vt_T=0, vt_hd=64, ln_part=None, ln_colsum=None, ln_eps=1e-5, ln_part_out=None):
+               vt=None, vt_col0=0, vt_T=0, vt_hd=64):
     """C = act(A @ W^T + bias) + residual on the fp16 matrix cores at fp32-class
     accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
     split-row form `out_split` of the result.  With `vt` the output columns from
@@ -267,16 +259,6 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     g.epi_act = act
     if vt is not None:
         g.Vt, g.vt_col0, g.vt_T, g.vt_hd = vt.data_ptr(), vt_col0, vt_T, vt_hd
-    if ln_part is not None:
-        # folded LayerNorm: a_split = un-normalised rows, w_split = gamma-scaled weights,
-        # bias = b + W beta, ln_colsum = row sums of the scaled weights, ln_part [M, parts, 2]
-        _chk_f32(ln_part, ln_colsum)
-        assert ln_part.is_contiguous() and ln_part.shape[0] == M and ln_part.shape[2] == 2
-        g.ln_part, g.ln_colsum, g.ln_parts, g.ln_eps = ln_part.data_ptr(), ln_colsum.data_ptr(), ln_part.shape[1], ln_eps
-    if ln_part_out is not None:
-        _chk_f32(ln_part_out)
-        assert ln_part_out.is_contiguous() and tuple(ln_part_out.shape) == (M, N // 32, 2)
-        g.ln_part_out = ln_part_out.data_ptr()
     lib = _lib.load()
     if _prof is not None:
         _prof['count'] += 1
@@ -340,17 +322,6 @@ def mha_noncausal_split(qkv, B, T, n_head, out_split):
     check(_lib.load().t2h_mha_noncausal_split_f32(_p(qkv), _p(out_split), B, T, n_head, _stream()),
           't2h_mha_noncausal_split_f32')
     return out_split
-
-
-def row_stats(x, out=None):
-    """x [rows, C] -> LayerNorm slab statistics [rows, C/32, 2] (sum, sumsq)."""
-    _chk_f32(x, out)
-    assert x.is_contiguous()
-    rows, C = x.shape
-    if out is None:
-        out = torch.empty((rows, C // 32, 2), device=x.device, dtype=torch.float32)
-    check(_lib.load().t2h_row_stats_f32(_p(x), _p(out), rows, C, _stream()), 't2h_row_stats_f32')
-    return out
 
 
 def groupnorm_tables(x, gamma, beta, n_img, hw, groups=32, eps=1e-6):

@@ -169,22 +169,6 @@ def pack_transformer(P, sd, dst='tf'):
                          ('fc2', f'{s}.mlp.2.weight')):
             w = P[f'{d}.qkv.w'].cpu() if key is None else sd[key]
             P.t[f'{d}.{lin}.w_split'] = _ops.pack_split_rows_host(w).to(P.device)
-        # LayerNorm folded into the following Linear for the fused-LN GEMM:
-        # LN(x) W^T + b = ((x-mean)*rstd) (W diag(gamma))^T + (b + W beta)
-        for ln, lin in (('ln1', 'qkv'), ('ln2', 'fc1')):
-            if lin == 'qkv':
-                w, b = P[f'{d}.qkv.w'].double().cpu(), P[f'{d}.qkv.b'].double().cpu()
-            else:
-                w, b = sd[f'{s}.mlp.0.weight'].double(), sd[f'{s}.mlp.0.bias'].double()
-            g, be = sd[f'{s}.{ln}.weight'].double(), sd[f'{s}.{ln}.bias'].double()
-            P.put(f'{d}.{lin}.w_ln', (w * g[None, :]).float())
-            P.put(f'{d}.{lin}.b_ln', (b + w @ be).float())
-            # the same for the split-precision GEMM (t2h_gemm_split_args.ln_part): split rows of
-            # the scaled weights and their row sums AS REPRESENTED by the two fp16 planes
-            wl = (w * g[None, :]).float()
-            P.t[f'{d}.{lin}.w_ln_split'] = _ops.pack_split_rows_host(wl).to(P.device)
-            hi, lo = _ops.split_planes_host(wl)
-            P.put(f'{d}.{lin}.colsum', (hi.double() + lo.double() / _ops.SPLIT_LO_SCALE).sum(1).float())
         P.put(f'{d}.proj.w', sd[f'{s}.attn.proj.weight'])
         P.put(f'{d}.proj.b', sd[f'{s}.attn.proj.bias'])
         P.put(f'{d}.fc1.w', sd[f'{s}.mlp.0.weight'])

@@ -13,11 +13,8 @@ VARIANTS = (('full', []), ('full+timing', ['-DT2H_MHA_TIMING']), ('noexp', ['-DT
             ('noexp+nosplit', ['-DT2H_MDBG_NOEXP', '-DT2H_MDBG_NOSPLIT']), ('nomma', ['-DT2H_MDBG_NOMMA']),
             ('nostage', ['-DT2H_MDBG_NOSTAGE']),
             ('mma only', ['-DT2H_MDBG_NOEXP', '-DT2H_MDBG_NOSPLIT', '-DT2H_MDBG_NOSTAGE']))
-if len(sys.argv) > 1 and sys.argv[1] == 'iglp':  # LLVM scheduling strategies (__builtin_amdgcn_iglp_opt)
-    VARIANTS = (('full', []), ) + tuple((f'iglp_opt({v})', [f'-DT2H_MHA_IGLP={v}']) for v in (0, 1, 2, 3)) + (('full again', []), )
-if len(sys.argv) > 1 and sys.argv[1] == 'barrier':  # per-half LDS-counter barrier variants
-    VARIANTS = (('full', []), ('no s_sleep in the spin', ['-DT2H_MHA_NOSLEEP']),
-                ('block barrier', ['-DT2H_MHA_BLOCK_BARRIER']), ('full again', []))
+if len(sys.argv) > 1 and sys.argv[1] == 'timing':
+    VARIANTS = (('full', []), ('full+timing', ['-DT2H_MHA_TIMING']), ('nomma', ['-DT2H_MDBG_NOMMA']), ('mma only', ['-DT2H_MDBG_NOEXP', '-DT2H_MDBG_NOSPLIT', '-DT2H_MDBG_NOSTAGE']))
 B, T, H, C = 8, 512, 8, 512
 for tag, extra in VARIANTS:
     so = '/tmp/libt2h_mab_' + ''.join(ch if ch.isalnum() else '_' for ch in tag) + '.so'
