@@ -89,6 +89,15 @@ int t2h_gemm_tile_config(const t2h_gemm_args* args);
  * supports it (-1 = automatic); returns the previous setting */
 int t2h_gemm_force_config(int cfg);
 
+/* The stride-1 convolutions of the hierarchical VQGAN decode (3x3 'same', 3x3 after nearest-x2
+ * upsample, 1x1) on the fp16 matrix cores at fp32-class accuracy: same arguments and meaning as
+ * t2h_gemm_f32 except that B points to the SPLIT-ROW weights [N][K/32][2][32] fp16 (t2h_split_rows_f32
+ * of the packed [N, K] matrix) and: a_mode 0 requires pro_rows (rows per image); pixels per image
+ * must be a multiple of 128; no b_trans / batch / alpha / stride 2 / GELU.  Activations (A, C,
+ * residual) stay fp32.  Replaces t2h_gemm_f32 at vqgan_arch.py:597-617,529-534,636-661,1000-1033,
+ * 1136-1151 (opt-out: T2H_SPLIT_CONV=0). */
+int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
+
 /* ------------------------------------------------- split-precision GEMM -----
  * Same contraction on the fp16 matrix cores at fp32-class accuracy: every fp32
  * operand is carried as two fp16 planes (x = h + l / 2048, h = fp16(x),

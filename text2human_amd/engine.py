@@ -23,6 +23,12 @@ class VQGANStack:
     def __init__(self, P, name, desc):
         self.P, self.name, self.desc = P, name, desc
 
+    def _ws(self, key, hw, mode='same'):
+        """Split-row weights of `key` if the stack was packed with them (weights.add_split_conv_weights)
+        and t2h_conv_split_f32 serves the shape, else None (-> exact-fp32 kernel)."""
+        ws = self.P.t.get(key + 's')
+        return ws if ws is not None and ops.conv_split_ok(hw, mode) else None
+
     def _gn(self, x, pfx, n_img, hw):
         P = self.P
         return ops.groupnorm_tables(x, P[f'{pfx}.g'], P[f'{pfx}.b'], n_img, hw)
@@ -36,27 +42,30 @@ class VQGANStack:
         cout = P[f'{pfx}.conv1.w'].shape[0]
         sc, sh = self._gn(x, f'{pfx}.norm1', n_img, h * w)
         t = ops.conv3x3(x, P[f'{pfx}.conv1.w'], n_img, h, w, cin, bias=P[f'{pfx}.conv1.b'],
-                        pro=(sc, sh, PRO_SWISH))
+                        pro=(sc, sh, PRO_SWISH), w_split=self._ws(f'{pfx}.conv1.w', h * w))
         sc, sh = self._gn(t, f'{pfx}.norm2', n_img, h * w)
         skip = x
         if f'{pfx}.nin.w' in P:
-            skip = ops.gemm(x, P[f'{pfx}.nin.w'], bias=P[f'{pfx}.nin.b'])
+            skip = ops.gemm(x, P[f'{pfx}.nin.w'], bias=P[f'{pfx}.nin.b'], w_split=self._ws(f'{pfx}.nin.w', h * w),
+                            rows_per_img=h * w)
         return ops.conv3x3(t, P[f'{pfx}.conv2.w'], n_img, h, w, cout, bias=P[f'{pfx}.conv2.b'],
-                           pro=(sc, sh, PRO_SWISH), residual=skip)
+                           pro=(sc, sh, PRO_SWISH), residual=skip, w_split=self._ws(f'{pfx}.conv2.w', h * w))
 
     def attnblock(self, x, pfx, n_img, n):
         """AttnBlock.forward (vqgan_arch.py:636-661)."""
         P = self.P
         c = x.shape[1]
         sc, sh = self._gn(x, f'{pfx}.norm', n_img, n)
-        qkv = ops.gemm(x, P[f'{pfx}.qkv.w'], bias=P[f'{pfx}.qkv.b'], pro=(sc, sh, n, PRO_NONE))
+        qkv = ops.gemm(x, P[f'{pfx}.qkv.w'], bias=P[f'{pfx}.qkv.b'], pro=(sc, sh, n, PRO_NONE),
+                       w_split=self._ws(f'{pfx}.qkv.w', n))
         q3 = qkv.view(n_img, n, 3 * c)
         s = torch.empty((n_img, n, n), device=x.device, dtype=torch.float32)
         ops.bgemm(q3[:, :, :c], q3[:, :, c:2 * c], s, alpha=float(int(c)**(-0.5)))
         ops.softmax_rows_(s)
         o = torch.empty((n_img, n, c), device=x.device, dtype=torch.float32)
         ops.bgemm(s, q3[:, :, 2 * c:], o, b_trans=True)
-        return ops.gemm(o.view(n_img * n, c), P[f'{pfx}.proj.w'], bias=P[f'{pfx}.proj.b'], residual=x)
+        return ops.gemm(o.view(n_img * n, c), P[f'{pfx}.proj.w'], bias=P[f'{pfx}.proj.b'], residual=x,
+                        w_split=self._ws(f'{pfx}.proj.w', n), rows_per_img=n)
 
     def _mid(self, h, n_img, hh, ww):
         nm = self.name
@@ -67,7 +76,9 @@ class VQGANStack:
     def _conv(self, x, pfx, n_img, h, w, mode='same', **kw):
         P = self.P
         cin = P[f'{pfx}.w'].shape[1] // 9
-        return ops.conv3x3(x, P[f'{pfx}.w'], n_img, h, w, cin, bias=P[f'{pfx}.b'], mode=mode, **kw)
+        hw_out = h * w * (4 if mode == 'up' else 1)
+        return ops.conv3x3(x, P[f'{pfx}.w'], n_img, h, w, cin, bias=P[f'{pfx}.b'], mode=mode,
+                           w_split=self._ws(f'{pfx}.w', hw_out, mode), **kw)
 
     def encode(self, x, n_img, h, w):
         """Encoder.forward (vqgan_arch.py:892-919); x rows [n_img*h*w, Cin_pad]."""

@@ -46,6 +46,13 @@ class BaseSampleModel():
         d_dec = weights.pack_vqgan(P, sds['decoder'], 'dec')
         d_res = weights.pack_vqgan(P, sds['bot_decoder_res'], 'res')
         d_enc = weights.pack_vqgan(P, sds['segm_encoder'], 'senc')
+        # T2H_SPLIT_CONV=0 keeps the decoders' convolutions on the exact-fp32 matrix instructions;
+        # default: split-precision (2 x fp16 planes, three products) like the sampler's Linears.
+        # The tokenizer encoder, the index-prediction UNet and the parsing generator stay exact
+        # fp32: their outputs are argmin / argmax decisions that must match the reference bit for bit.
+        if os.environ.get('T2H_SPLIT_CONV', '1') != '0':
+            weights.add_split_conv_weights(P, 'dec')
+            weights.add_split_conv_weights(P, 'res')
         self.decoder = engine.VQGANStack(P, 'dec', d_dec)
         self.bot_decoder_res = engine.VQGANStack(P, 'res', d_res)
         self.segm_encoder = engine.VQGANStack(P, 'senc', d_enc)

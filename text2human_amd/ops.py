@@ -98,12 +98,14 @@ def _launch_gemm(g, what):
 
 
 def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=None,
-         b_trans=False):
+         b_trans=False, w_split=None, rows_per_img=0):
     """out[M,N] = act(alpha * pro(a)[M,K] @ w[N,K]^T + bias) + residual.
 
     a, w, out, residual: 2-D views with unit inner stride (row stride free).
     pro = (scale[n_img,K], shift[n_img,K], rows_per_img, pro_act).
-    b_trans: w is given as [K,N]."""
+    b_trans: w is given as [K,N].
+    w_split (split rows of w) + rows_per_img: the product runs on the fp16 matrix cores
+    (t2h_conv_split_f32, 1x1 mode) instead of the fp32 ones."""
     _chk_f32(a, w, out, bias, residual)
     M, K = a.shape
     N = w.shape[1] if b_trans else w.shape[0]
@@ -124,8 +126,34 @@ def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_rows, g.pro_ld, g.pro_act = rows, sc.shape[1], pact
     g.batch = 1
+    if w_split is not None:
+        assert not b_trans and alpha == 1.0 and act in (ACT_NONE, ACT_RELU)
+        g.B = w_split.data_ptr()
+        g.pro_rows = g.pro_rows or rows_per_img
+        _launch_conv_split(g, 2.0 * M * N * K)
+        return out
     _launch_gemm(g, 't2h_gemm_f32')
     return out
+
+
+def _launch_conv_split(g, flops):
+    lib = _lib.load()
+    if _prof is not None:
+        _prof['count'] += 1
+        if _prof['count'] % _prof['every'] == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.t2h_conv_split_f32(ctypes.byref(g), _stream()), 't2h_conv_split_f32')
+            e1.record()
+            _prof['recs'].append(('conv_split_kernel<2xfp16>', flops, e0, e1))
+            return
+    check(lib.t2h_conv_split_f32(ctypes.byref(g), _stream()), 't2h_conv_split_f32')
+
+
+def conv_split_ok(n_pix_per_img, mode='same', act=ACT_NONE):
+    """Shapes t2h_conv_split_f32 serves: stride-1 convolutions whose images hold a multiple of
+    128 pixels (a workgroup never straddles two images)."""
+    return mode in ('same', 'up') and n_pix_per_img % 128 == 0 and act in (ACT_NONE, ACT_RELU)
 
 
 def bgemm(a, w, out, alpha=1.0, b_trans=False):
@@ -146,7 +174,7 @@ def bgemm(a, w, out, alpha=1.0, b_trans=False):
 
 
 def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=ACT_NONE,
-            pro=None, mode='same', res_pre=False):
+            pro=None, mode='same', res_pre=False, w_split=None):
     """3x3 convolution of an NHWC image held as pixel rows x [n_img*hin*win, >=cin]
     with packed weights w [Cout, 9*cin] ([tap][cin] order).
 
@@ -180,6 +208,10 @@ def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=
         _chk_f32(sc, sh)
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_ld, g.pro_act = sc.shape[1], pact
+    if w_split is not None:  # split rows of w: fp16 matrix cores, fp32-class accuracy
+        g.B = w_split.data_ptr()
+        _launch_conv_split(g, 2.0 * M * N * 9 * cin)
+        return out
     _launch_gemm(g, 't2h_gemm_f32(conv)')
     return out
 

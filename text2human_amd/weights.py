@@ -150,6 +150,20 @@ def pack_vqgan(P, sd, dst):
     return desc
 
 
+def add_split_conv_weights(P, dst):
+    """Split rows (2 x fp16 planes, t2h_conv_split_f32) of every packed conv / 1x1 matrix under
+    `dst.` whose shape the kernel serves (K % 32 == 0, Cout % 8 == 0), stored next to the fp32
+    matrix as `<name>.ws`.  Split on the device (bit-identical to ops.pack_split_rows_host); a
+    weight outside fp16's range raises."""
+    from . import engine, ops
+    ops.split_overflow(reset=True)
+    for k in [k for k in P.t if k.startswith(dst + '.') and k.endswith('.w')]:
+        w = P.t[k]
+        if w.dim() == 2 and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0:
+            P.t[k + 's'] = ops.split_rows(w)
+    engine.check_split_overflow(f'weights of {dst}')
+
+
 def pack_transformer(P, sd, dst='tf'):
     n_layers = _count(sd, 'blocks')
     P.put(f'{dst}.tok_emb', sd['tok_emb.weight'])
