@@ -90,13 +90,20 @@ int t2h_gemm_tile_config(const t2h_gemm_args* args);
 int t2h_gemm_force_config(int cfg);
 
 /* The stride-1 convolutions of the hierarchical VQGAN decode (3x3 'same', 3x3 after nearest-x2
- * upsample, 1x1) on the fp16 matrix cores at fp32-class accuracy: same arguments and meaning as
- * t2h_gemm_f32 except that B points to the SPLIT-ROW weights [N][K/32][2][32] fp16 (t2h_split_rows_f32
- * of the packed [N, K] matrix) and: a_mode 0 requires pro_rows (rows per image); pixels per image
- * must be a multiple of 128; no b_trans / batch / alpha / stride 2 / GELU.  Activations (A, C,
- * residual) stay fp32.  Replaces t2h_gemm_f32 at vqgan_arch.py:597-617,529-534,636-661,1000-1033,
- * 1136-1151 (opt-out: T2H_SPLIT_CONV=0). */
+ * upsample, 1x1) on the fp16 matrix cores at fp32-class accuracy.  Arguments as t2h_gemm_f32 except:
+ * A points to the SPLIT-ROW activations [pixel][Cin/32][2][32] fp16 (t2h_gn_apply_split_f32 /
+ * t2h_split_rows_f32; lda unused), B to the split-row weights [N][K/32][2][32]; no prologue tables
+ * (GroupNorm + swish are applied by the pass that writes A); a_mode 1 geometry always (a 1x1
+ * convolution is K == Cin, pad 0); pixels per image must be a multiple of 128; no b_trans / batch / alpha / stride 2 / GELU.
+ * C, residual, bias stay fp32.  Replaces t2h_gemm_f32 at vqgan_arch.py:597-617,529-534,636-661,
+ * 1000-1033,1136-1151 (opt-out: T2H_SPLIT_CONV=0). */
 int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
+/* out_split[row] = split( act( x[row] * scale[img] + shift[img] ) ): GroupNorm apply (tables of
+ * t2h_groupnorm_tables_f32; NULL = plain split) + swish (act 1) of fp32 NHWC rows in one pass
+ * (vqgan_arch.py:510-517,599-600,609-610,637,1026-1027) */
+int t2h_gn_apply_split_f32(const float* x, int32_t ldx, const float* scale, const float* shift, int32_t tbl_ld,
+                           uint16_t* out_split, int64_t rows, int32_t rows_per_img, int32_t C, int32_t act,
+                           void* stream);
 
 /* ------------------------------------------------- split-precision GEMM -----
  * Same contraction on the fp16 matrix cores at fp32-class accuracy: every fp32

@@ -40,33 +40,41 @@ def test_conv3x3_split(mode, cin, cout, h, w):
         if use_pro:
             xin = xin * sc.double()[:, :, None, None] + sh.double()[:, :, None, None]
             xin = xin * torch.sigmoid(xin)
+        # the elementwise pass is bitwise the split of the fp32 kernel's operand prologue
+        xs = (ops.gn_apply_split(rows, sc.to(DEV), sh.to(DEV), rows_per_img=h * w, act=ops.PRO_SWISH) if use_pro
+              else ops.gn_apply_split(rows))
+        got = ops.unsplit_rows_host(xs, n_img * h * w, cin).double()
+        want = xin.permute(0, 2, 3, 1).reshape(-1, cin)
+        assert ((got - want).abs() <= 2e-6 + 2e-6 * want.abs()).all()
         if mode == 'up':
             xin = F.interpolate(xin, scale_factor=2.0, mode='nearest')
         ref = F.conv2d(xin, wt.double(), b.double(), 1, 1)
         ho, wo = ref.shape[2:]
         assert ops.conv_split_ok(ho * wo, mode)
         res = rnd(n_img * ho * wo, cout, seed=18)
-        kw = dict(bias=b.to(DEV), residual=res.to(DEV), mode=mode,
-                  pro=(sc.to(DEV), sh.to(DEV), ops.PRO_SWISH) if use_pro else None)
-        out = ops.conv3x3(rows, wp, n_img, h, w, cin, w_split=ws, **kw)
+        out = ops.conv_split(xs, ws, n_img, h, w, cin, cout, bias=b.to(DEV), residual=res.to(DEV), mode=mode)
         ref_rows = ref.permute(0, 2, 3, 1).reshape(-1, cout) + res.double()
         assert_close(out, ref_rows, what=f'{mode} pro={use_pro}')
         # and no worse than twice the exact-fp32 kernel's own distance from fp64
-        e32 = (ops.conv3x3(rows, wp, n_img, h, w, cin, **kw).cpu().double() - ref_rows).abs().max().item()
+        o32 = ops.conv3x3(rows, wp, n_img, h, w, cin, bias=b.to(DEV), residual=res.to(DEV), mode=mode,
+                          pro=(sc.to(DEV), sh.to(DEV), ops.PRO_SWISH) if use_pro else None)
+        e32 = (o32.cpu().double() - ref_rows).abs().max().item()
         es = (out.cpu().double() - ref_rows).abs().max().item()
         assert es <= 2 * e32 + 1e-6, (es, e32)
 
 
-def test_conv1x1_split_with_and_without_groupnorm_prologue():
+def test_conv1x1_split_with_and_without_groupnorm():
     n_img, hw, C, N = 3, 512, 256, 768
     x, w, b = rnd(n_img * hw, C, seed=8), rnd(N, C, seed=9, scale=0.1), rnd(N, seed=12)
     sc, sh = rnd(n_img, C, seed=10) * 0.5 + 1, rnd(n_img, C, seed=11)
     ws = ops.split_rows(w.to(DEV))
     xa = (x.view(n_img, hw, C) * sc[:, None] + sh[:, None]).double().view(-1, C)
-    out = ops.gemm(x.to(DEV), w.to(DEV), bias=b.to(DEV), pro=(sc.to(DEV), sh.to(DEV), hw, ops.PRO_NONE), w_split=ws)
-    assert_close(out, xa @ w.double().t() + b.double(), what='GN prologue')
+    xs = ops.gn_apply_split(x.to(DEV), sc.to(DEV), sh.to(DEV), rows_per_img=hw)
+    out = ops.conv_split(xs, ws, n_img, hw, 1, C, N, taps=1, bias=b.to(DEV))
+    assert_close(out, xa @ w.double().t() + b.double(), what='GN apply')
     res = rnd(n_img * hw, N, seed=13)
-    out = ops.gemm(x.to(DEV), w.to(DEV), bias=b.to(DEV), residual=res.to(DEV), w_split=ws, rows_per_img=hw)
+    out = ops.conv_split(ops.gn_apply_split(x.to(DEV)), ws, n_img, hw, 1, C, N, taps=1, bias=b.to(DEV),
+                         residual=res.to(DEV))
     assert_close(out, x.double() @ w.double().t() + b.double() + res.double(), what='plain + residual')
 
 
@@ -74,8 +82,11 @@ def test_conv_split_rejects_what_it_does_not_serve():
     from text2human_amd import _lib
     x, w = rnd(2 * 96, 64, seed=1).to(DEV), rnd(64, 64, seed=2).to(DEV)
     with pytest.raises(_lib.T2HError, match='multiple of 128'):
-        ops.gemm(x, w, w_split=ops.split_rows(w), rows_per_img=96)
+        ops.conv_split(ops.gn_apply_split(x), ops.split_rows(w), 2, 96, 1, 64, 64, taps=1)
     assert not ops.conv_split_ok(96) and not ops.conv_split_ok(512, 'down')
+    ops.split_overflow(reset=True)
+    ops.gn_apply_split(x * 1e5)
+    assert ops.split_overflow(reset=True)
 
 
 def test_decode_with_split_convs_vs_reference_golden():

@@ -9,22 +9,21 @@
 // (:597-617), Upsample (:529-534), conv_in, the AttnBlock 1x1 projections (:636-661) -- 563 GFLOP
 // per image that ran at the fp32 matrix rate (157 TFLOP/s peak; 85-117 measured).
 //
-//  * Weights are split rows [Cout][K/32][2][32] fp16, packed once by the host; a K tile (32
-//    channels of one tap) of a weight row is one 128-byte line = eight 16-byte pieces.
-//  * Activations stay fp32 in HBM (GroupNorm statistics and the residual stream need them).  A
-//    thread stages 16-byte pieces (4 channels of one pixel); when a piece is written to LDS it is
-//    GroupNorm-applied (per-(image, channel) scale / shift), swish-ed, zeroed where the tap falls
-//    outside the image (the reference pads the ACTIVATED tensor) and split into the two fp16 planes
-//    -- two 8-byte LDS writes.  LDS rows = [hi plane 64 B | lo plane 64 B | 16 B pad] like
-//    gemm_split.hip, so the fragment reads are the same conflict-free 16-byte reads.
+//  * BOTH operands are split rows (gemm_split.hip's format): weights [Cout][K/32][2][32] fp16, packed
+//    once; activations [pixel][Cin/32][2][32] fp16, written by t2h_gn_apply_split_f32 (GroupNorm
+//    apply + swish + split in ONE elementwise pass over the fp32 tensor) or t2h_split_rows_f32.  A K
+//    tile (32 channels of one tap) of a pixel or of a weight row is one 128-byte line = eight
+//    16-byte pieces that go global -> register -> LDS untouched; the only per-piece work is the
+//    im2col address (tap shift, nearest-x2 upsample) and zeroing where the tap leaves the image.
+//    (First version: fp32 activations with GroupNorm + swish + split applied while staging -- 9 taps
+//    x Cout/128 column tiles times per element.  That kernel was VALU-bound: 207 VALU + 16
+//    transcendental instructions per wave and K tile against 12 matrix instructions, 153 TFLOP/s
+//    fp32-equivalent on the 128->128 @512x256 layer; profiles/r02_decode_kernel_stats.md.)
 //  * Main loop: gemm_split.hip's two-register-set, counted-vmcnt pipeline (tiles kt+1 and kt+2 in
 //    flight in registers while tile kt is multiplied; every staged piece is waited for with an
-//    exact vmcnt, converted, written and re-issued in the shadow of the matrix instructions).
-//  * 128x128 tile, 8 waves (32x64 wave tiles): 74 KB of LDS and ~170 registers, two workgroups per
-//    CU -- the staging side is VALU-heavy (swish + split per element and tap), and a second
-//    workgroup's matrix instructions cover it.
-//  * A workgroup must lie inside one image (rows per image % 128 == 0: every decode shape), so the
-//    scale / shift of a K tile is one 16-byte pair per thread.
+//    exact vmcnt, written and re-issued in the shadow of the matrix instructions).
+//  * 128x128 tile, 8 waves (32x64 wave tiles), 74 KB of LDS.
+//  * A workgroup must lie inside one image (pixels per image % 128 == 0: every decode shape).
 #include <type_traits>
 
 #include "common.h"
@@ -33,7 +32,6 @@ namespace {
 
 typedef t2h_f16x8 f16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CS_BM = 128, CS_BN = 128, CS_WM = 4, CS_WN = 2, CS_NT = 64 * CS_WM * CS_WN;
 constexpr int CS_LDS_ROW = 144;                     // bytes per tile row in LDS
@@ -50,13 +48,7 @@ __device__ __forceinline__ void cs_wait(u32x4& v) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
-constexpr size_t cs_main_lds_bytes() {
-  constexpr int buf = 2 * (CS_BM + CS_BN) * CS_LDS_ROW;
-  constexpr int epi = (CS_BM / CS_WM) * (CS_BN / CS_WN + 4) * 4 * CS_WM * CS_WN;
-  return buf > epi ? buf : epi;
-}
-
-__global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_args p, int* const ovf) {
+__global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_args p) {
   constexpr int WM = CS_BM / CS_WM, WN = CS_BN / CS_WN;  // 32 x 64 wave tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int BUF_B = (CS_BM + CS_BN) * CS_LDS_ROW;
@@ -64,11 +56,8 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
   constexpr int OW = WM * O_LD;
   constexpr int EPI_B = OW * 4 * CS_WM * CS_WN;
   constexpr int SMEM_B = 2 * BUF_B > EPI_B ? 2 * BUF_B : EPI_B;
-  static_assert(SMEM_B == (int)cs_main_lds_bytes(), "LDS size bookkeeping");
   constexpr int NMMA = 2 * 3 * TM * TN;  // matrix instructions per wave and K tile
-  // tile buffers / epilogue staging, then this image's scale | shift rows (Cin floats each)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const tbl = reinterpret_cast<float*>(smem + SMEM_B);
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -88,8 +77,8 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
   const int hw = p.Hout * p.Wout;
   const int img = m0 / hw;       // the whole workgroup lies in this image (host-checked)
   const int Hlim = p.Hin << p.ups, Wlim = p.Win << p.ups;
-  const bool pro = p.pro_scale != nullptr;
-  const int pc = tid & 7;        // this thread's 16-byte piece (4 channels) inside a K tile, A and B alike
+  const int pc = tid & 7;        // this thread's 16-byte piece inside a K tile, A and B alike
+  const int ctiles = p.Cin / 32; // K tiles per tap
 
   // ---- A rows of this thread (output pixels) and B rows (output channels)
   int a_y[CS_LA], a_x[CS_LA];
@@ -101,7 +90,8 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
     a_y[i] = m < p.M ? oy - p.pad : -(1 << 28);
     a_x[i] = ox - p.pad;
   }
-  const float* const a_img = p.A + (int64_t)img * p.Hin * p.Win * p.lda + pc * 4;
+  const int64_t arow_b = (int64_t)ctiles * T2H_SPLIT_TILE_B;  // bytes per pixel of the split-row activations
+  const char* const a_img = reinterpret_cast<const char*>(p.A) + (int64_t)img * p.Hin * p.Win * arow_b + pc * 16;
   const int64_t brow_b = (int64_t)nk * T2H_SPLIT_TILE_B;
   const char* b_src[CS_LB];
 #pragma unroll
@@ -109,37 +99,21 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
     const int n = min(n0 + (tid >> 3) + (CS_NT / 8) * i, p.N - 1);  // clamped: extra columns are never stored
     b_src[i] = reinterpret_cast<const char*>(p.B) + (int64_t)n * brow_b + pc * 16;
   }
-  if (pro) {  // the image's GroupNorm tables -> LDS: read per K tile without touching the vmcnt queue
-    for (int c = tid * 4; c < p.Cin; c += CS_NT * 4) {
-      *reinterpret_cast<f32x4*>(tbl + c) = *reinterpret_cast<const f32x4*>(p.pro_scale + (int64_t)img * p.pro_ld + c);
-      *reinterpret_cast<f32x4*>(tbl + p.Cin + c) =
-          *reinterpret_cast<const f32x4*>(p.pro_shift + (int64_t)img * p.pro_ld + c);
-    }
-    __syncthreads();
-  }
-
-  // register sets: L pieces + the tile's scale / shift quads + validity bits of the A pieces
+  // register sets: L pieces + validity bits of the A pieces
   u32x4 rg[2][CS_L];
-  f32x4 sc[2], sh[2];
   unsigned valid[2] = {0u, 0u};
 
   auto issue_piece = [&](auto setc, int q, int kt) {
     constexpr int S = decltype(setc)::value;
     const int k = min(kt, last);
     if (q < CS_LA) {
-      const int tap = (k * 32) / p.Cin, c0 = k * 32 - tap * p.Cin;
+      const int tap = k / ctiles, ct = k - tap * ctiles;  // wave-uniform
       const int dy = taps == 9 ? tap / 3 : 0, dx = taps == 9 ? tap - 3 * (tap / 3) : 0;
       const int iy = a_y[q] + dy, ix = a_x[q] + dx;
       const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
       const int cy = min(max(iy, 0), Hlim - 1) >> p.ups, cx = min(max(ix, 0), Wlim - 1) >> p.ups;
-      cs_gload16(rg[S][q], a_img + ((int64_t)cy * p.Win + cx) * p.lda + c0);
+      cs_gload16(rg[S][q], a_img + ((int64_t)cy * p.Win + cx) * arow_b + ct * T2H_SPLIT_TILE_B);
       valid[S] = (valid[S] & ~(1u << q)) | ((ok ? 1u : 0u) << q);
-      // the tile's scale / shift quads, used two tiles later; replaced only once the LAST A piece
-      // of the set has been converted with the old ones (pieces are put + re-issued one by one)
-      if (q == CS_LA - 1 && pro) {
-        sc[S] = *reinterpret_cast<const f32x4*>(tbl + c0 + pc * 4);
-        sh[S] = *reinterpret_cast<const f32x4*>(tbl + p.Cin + c0 + pc * 4);
-      }
     } else {
       cs_gload16(rg[S][q], b_src[q - CS_LA] + (int64_t)k * T2H_SPLIT_TILE_B);
     }
@@ -147,34 +121,15 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
   auto put_piece = [&](auto setc, int q, int buf) {
     constexpr int S = decltype(setc)::value;
     char* const base = smem + buf * BUF_B;
-    if (q < CS_LA) {
-      const f32x4 raw = __builtin_bit_cast(f32x4, rg[S][q]);
+    if (q < CS_LA) {  // zero where the tap falls outside the image (the reference pads the activated tensor)
       const bool ok = (valid[S] >> q) & 1u;
-      f32x4 v;
+      u32x4 v = rg[S][q];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float x = raw[e];
-        if (pro) {
-          x = fmaf(x, sc[S][e], sh[S][e]);
-          if (p.pro_act == 1) x = x / (1.0f + fast_exp(fminf(-x, 87.0f)));
-        }
-        v[e] = ok ? x : 0.f;
-      }
-      t2h_split_guard4(ovf, v);
-      t2h_f16x4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        _Float16 a, b;
-        t2h_split2(v[e], a, b);
-        h[e] = a;
-        l[e] = b;
-      }
-      char* d = base + ((tid >> 3) + (CS_NT / 8) * q) * CS_LDS_ROW + pc * 8;
-      *reinterpret_cast<t2h_f16x4*>(d) = h;
-      *reinterpret_cast<t2h_f16x4*>(d + T2H_SPLIT_PLANE_B) = l;
+      for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0u;
+      *reinterpret_cast<u32x4*>(base + ((tid >> 3) + (CS_NT / 8) * q) * CS_LDS_ROW + pc * 16) = v;
     } else {
-      char* d = base + (CS_BM + (tid >> 3) + (CS_NT / 8) * (q - CS_LA)) * CS_LDS_ROW + pc * 16;
-      *reinterpret_cast<u32x4*>(d) = rg[S][q];
+      *reinterpret_cast<u32x4*>(base + (CS_BM + (tid >> 3) + (CS_NT / 8) * (q - CS_LA)) * CS_LDS_ROW + pc * 16) =
+          rg[S][q];
     }
   };
 
@@ -321,15 +276,7 @@ extern "C" int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream) {
   t2h_gemm_args a = *args;
   T2H_REQUIRE(a.A && a.B && a.C, "t2h_conv_split_f32: NULL operand");
   T2H_REQUIRE(a.batch <= 1 && !a.b_trans && a.alpha == 1.0f, "t2h_conv_split_f32: plain single problem only");
-  if (a.a_mode == 0) {  // 1x1: a row-major [M, K] matrix is a 1-tap image of H x W = pro_rows x 1 pixels
-    T2H_REQUIRE(a.pro_rows > 0 && a.M % a.pro_rows == 0, "t2h_conv_split_f32: 1x1 mode needs rows per image (pro_rows)");
-    a.Cin = a.K;
-    a.Hin = a.Hout = a.pro_rows;
-    a.Win = a.Wout = 1;
-    a.pad = 0;
-    a.ups = 0;
-    a.stride = 1;
-  }
+  T2H_REQUIRE(a.a_mode == 1, "t2h_conv_split_f32: conv geometry required (a 1x1 convolution is K == Cin, pad 0)");
   T2H_REQUIRE(a.M > 0 && a.N > 0 && a.Cin > 0 && a.Cin % 32 == 0 && (a.K == a.Cin || a.K == 9 * a.Cin),
               "t2h_conv_split_f32: bad shape M=%d N=%d K=%d Cin=%d", a.M, a.N, a.K, a.Cin);
   T2H_REQUIRE(a.stride == 1 && (a.ups == 0 || a.ups == 1) && a.pad == (a.K == a.Cin ? 0 : 1),
@@ -337,20 +284,15 @@ extern "C" int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream) {
   T2H_REQUIRE(a.Hout == (a.Hin << a.ups) && a.Wout == (a.Win << a.ups) && a.M % (a.Hout * a.Wout) == 0,
               "t2h_conv_split_f32: geometry");
   T2H_REQUIRE((a.Hout * a.Wout) % CS_BM == 0, "t2h_conv_split_f32: pixels per image must be a multiple of %d", CS_BM);
-  T2H_REQUIRE(a.N % 8 == 0 && a.lda % 4 == 0 && a.ldc % 4 == 0 && (!a.residual || a.ldr % 4 == 0) &&
+  T2H_REQUIRE(a.N % 8 == 0 && a.ldc % 4 == 0 && (!a.residual || a.ldr % 4 == 0) &&
                   t2h_aligned16(a.A) && t2h_aligned16(a.B) && t2h_aligned16(a.C) &&
                   (!a.residual || t2h_aligned16(a.residual)),
               "t2h_conv_split_f32: N %% 8, leading dimensions %% 4, 16-byte aligned pointers");
   T2H_REQUIRE(a.epi_act == 0 || a.epi_act == 2, "t2h_conv_split_f32: epilogue activation none / ReLU");
-  if (a.pro_scale)
-    T2H_REQUIRE(a.pro_shift && a.pro_ld % 4 == 0 && t2h_aligned16(a.pro_scale) && t2h_aligned16(a.pro_shift),
-                "t2h_conv_split_f32: prologue tables");
-  int* ovf = t2h_split_overflow_flag_ptr();
-  T2H_REQUIRE(ovf != nullptr, "t2h_conv_split_f32: no overflow flag");
+  T2H_REQUIRE(a.pro_scale == nullptr && a.pro_shift == nullptr,
+              "t2h_conv_split_f32: no prologue tables (apply GroupNorm with t2h_gn_apply_split_f32)");
   dim3 grid(((a.N + CS_BN - 1) / CS_BN) * ((a.M + CS_BM - 1) / CS_BM)), block(CS_NT);
-  const size_t lds = cs_main_lds_bytes() + (a.pro_scale ? (size_t)2 * a.Cin * sizeof(float) : 0);
-  T2H_REQUIRE(lds <= 80 * 1024, "t2h_conv_split_f32: Cin=%d too large for the LDS table", a.Cin);
-  hipLaunchKernelGGL(conv_split_kernel, grid, block, lds, static_cast<hipStream_t>(stream), a, ovf);
+  hipLaunchKernelGGL(conv_split_kernel, grid, block, 0, static_cast<hipStream_t>(stream), a);
   T2H_CHECK_LAUNCH("t2h_conv_split_f32");
   return T2H_OK;
 }

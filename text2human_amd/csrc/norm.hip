@@ -70,6 +70,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// GroupNorm apply (+ swish) + split in one elementwise pass: fp32 NHWC rows -> split rows, the
+// operand format of t2h_conv_split_f32.  One thread per 8 consecutive channels of a pixel.
+__global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int tbl_ld,
+                                                             int rows_per_img, int C, int act,
+                                                             uint16_t* __restrict__ out, int64_t total, int* ovf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c8 = C >> 3;
+  const int64_t row = i / c8;
+  const int c0 = (int)(i - row * c8) * 8;
+  const float* xp = x + row * ldx + c0;
+  f32x4 va = *reinterpret_cast<const f32x4*>(xp), vb = *reinterpret_cast<const f32x4*>(xp + 4);
+  if (scale) {
+    const int64_t o = (row / rows_per_img) * tbl_ld + c0;
+    const f32x4 sa = *reinterpret_cast<const f32x4*>(scale + o), sb = *reinterpret_cast<const f32x4*>(scale + o + 4);
+    const f32x4 ta = *reinterpret_cast<const f32x4*>(shift + o), tb = *reinterpret_cast<const f32x4*>(shift + o + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      va[e] = fmaf(va[e], sa[e], ta[e]);
+      vb[e] = fmaf(vb[e], sb[e], tb[e]);
+      if (act == 1) {  // swish, same expression as the fp32 kernel's operand prologue (gemm.hip)
+        va[e] = va[e] / (1.0f + fast_exp(fminf(-va[e], 87.0f)));
+        vb[e] = vb[e] / (1.0f + fast_exp(fminf(-vb[e], 87.0f)));
+      }
+    }
+  }
+  t2h_store_split8(out, row, C, c0, va, vb, ovf);
+}
+
 // ---- GroupNorm statistics.  Grid (chunks, n_img).  Thread t owns the channel
 // quad (t % (C/4)) and walks pixels with stride 256/(C/4); per-channel partial
 // sums in fp64 (fp64 VALU is cheap on CDNA and removes the E[x^2]-E[x]^2
@@ -276,5 +307,26 @@ extern "C" int t2h_softmax_rows_f32(float* x, int32_t rows, int32_t n, int32_t l
     return T2H_ERR_UNSUPPORTED;
   }
   T2H_CHECK_LAUNCH("t2h_softmax_rows_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_gn_apply_split_f32(const float* x, int32_t ldx, const float* scale, const float* shift,
+                                      int32_t tbl_ld, uint16_t* out_split, int64_t rows, int32_t rows_per_img,
+                                      int32_t C, int32_t act, void* stream) {
+  T2H_REQUIRE(x && out_split && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0 && t2h_aligned16(x) &&
+                  t2h_aligned16(out_split),
+              "t2h_gn_apply_split_f32: bad arguments (C %% 32, ldx %% 4, 16-byte alignment)");
+  T2H_REQUIRE((scale == nullptr) == (shift == nullptr) && (act == 0 || act == 1),
+              "t2h_gn_apply_split_f32: scale / shift come together; act none / swish");
+  if (scale)
+    T2H_REQUIRE(rows_per_img > 0 && tbl_ld % 4 == 0 && t2h_aligned16(scale) && t2h_aligned16(shift),
+                "t2h_gn_apply_split_f32: tables");
+  int* ovf = t2h_split_overflow_flag_ptr();
+  T2H_REQUIRE(ovf != nullptr, "t2h_gn_apply_split_f32: no overflow flag");
+  const int64_t total = rows * (C / 8);
+  hipLaunchKernelGGL(gn_apply_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, ldx, scale, shift, tbl_ld, rows_per_img > 0 ? rows_per_img : 1,
+                     C, act, out_split, total, ovf);
+  T2H_CHECK_LAUNCH("t2h_gn_apply_split_f32");
   return T2H_OK;
 }

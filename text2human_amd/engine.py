@@ -33,39 +33,55 @@ class VQGANStack:
         P = self.P
         return ops.groupnorm_tables(x, P[f'{pfx}.g'], P[f'{pfx}.b'], n_img, hw)
 
-    def resblock(self, x, pfx, n_img, h, w):
-        """ResnetBlock.forward (vqgan_arch.py:597-617): both GroupNorm+swish are
-        fused into the following conv's operand load, bias + skip into its
-        epilogue."""
+    def _norm_conv3x3(self, x, norm, conv, n_img, h, w, mode='same', residual=None):
+        """conv(swish(GroupNorm(x))) (+ residual): GroupNorm + swish fused into the conv's operand
+        staging (exact-fp32 kernel), or -- split path -- applied by ONE elementwise pass that also
+        writes the two fp16 planes the split-precision conv reads (norm None: plain conv)."""
         P = self.P
-        cin = P[f'{pfx}.conv1.w'].shape[1] // 9
-        cout = P[f'{pfx}.conv1.w'].shape[0]
-        sc, sh = self._gn(x, f'{pfx}.norm1', n_img, h * w)
-        t = ops.conv3x3(x, P[f'{pfx}.conv1.w'], n_img, h, w, cin, bias=P[f'{pfx}.conv1.b'],
-                        pro=(sc, sh, PRO_SWISH), w_split=self._ws(f'{pfx}.conv1.w', h * w))
-        sc, sh = self._gn(t, f'{pfx}.norm2', n_img, h * w)
+        cin = P[f'{conv}.w'].shape[1] // 9
+        cout = P[f'{conv}.w'].shape[0]
+        hw_out = h * w * (4 if mode == 'up' else 1)
+        ws = self._ws(f'{conv}.w', hw_out, mode)
+        pro = self._gn(x, norm, n_img, h * w) if norm is not None else None
+        if ws is not None:
+            xs = ops.gn_apply_split(x, *(pro or (None, None)), rows_per_img=h * w,
+                                    act=PRO_SWISH if pro is not None else PRO_NONE)
+            return ops.conv_split(xs, ws, n_img, h, w, cin, cout, bias=P[f'{conv}.b'], residual=residual, mode=mode)
+        return ops.conv3x3(x, P[f'{conv}.w'], n_img, h, w, cin, bias=P[f'{conv}.b'], mode=mode, residual=residual,
+                           pro=(pro[0], pro[1], PRO_SWISH) if pro is not None else None)
+
+    def _conv1x1(self, x, key, n_rows_img, pro=None, residual=None):
+        """1x1 convolution of pixel rows (pro = GroupNorm tables applied without activation)."""
+        P = self.P
+        ws = self._ws(f'{key}.w', n_rows_img)
+        if ws is not None:
+            xs = ops.gn_apply_split(x, *(pro or (None, None)), rows_per_img=n_rows_img)
+            cout, cin = P[f'{key}.w'].shape
+            return ops.conv_split(xs, ws, x.shape[0] // n_rows_img, n_rows_img, 1, cin, cout, taps=1,
+                                  bias=P[f'{key}.b'], residual=residual)
+        return ops.gemm(x, P[f'{key}.w'], bias=P[f'{key}.b'], residual=residual,
+                        pro=(pro[0], pro[1], n_rows_img, PRO_NONE) if pro is not None else None)
+
+    def resblock(self, x, pfx, n_img, h, w):
+        """ResnetBlock.forward (vqgan_arch.py:597-617): GroupNorm + swish go with the following conv's
+        operand, bias + skip into its epilogue."""
+        t = self._norm_conv3x3(x, f'{pfx}.norm1', f'{pfx}.conv1', n_img, h, w)
         skip = x
-        if f'{pfx}.nin.w' in P:
-            skip = ops.gemm(x, P[f'{pfx}.nin.w'], bias=P[f'{pfx}.nin.b'], w_split=self._ws(f'{pfx}.nin.w', h * w),
-                            rows_per_img=h * w)
-        return ops.conv3x3(t, P[f'{pfx}.conv2.w'], n_img, h, w, cout, bias=P[f'{pfx}.conv2.b'],
-                           pro=(sc, sh, PRO_SWISH), residual=skip, w_split=self._ws(f'{pfx}.conv2.w', h * w))
+        if f'{pfx}.nin.w' in self.P:
+            skip = self._conv1x1(x, f'{pfx}.nin', h * w)
+        return self._norm_conv3x3(t, f'{pfx}.norm2', f'{pfx}.conv2', n_img, h, w, residual=skip)
 
     def attnblock(self, x, pfx, n_img, n):
         """AttnBlock.forward (vqgan_arch.py:636-661)."""
-        P = self.P
         c = x.shape[1]
-        sc, sh = self._gn(x, f'{pfx}.norm', n_img, n)
-        qkv = ops.gemm(x, P[f'{pfx}.qkv.w'], bias=P[f'{pfx}.qkv.b'], pro=(sc, sh, n, PRO_NONE),
-                       w_split=self._ws(f'{pfx}.qkv.w', n))
+        qkv = self._conv1x1(x, f'{pfx}.qkv', n, pro=self._gn(x, f'{pfx}.norm', n_img, n))
         q3 = qkv.view(n_img, n, 3 * c)
         s = torch.empty((n_img, n, n), device=x.device, dtype=torch.float32)
         ops.bgemm(q3[:, :, :c], q3[:, :, c:2 * c], s, alpha=float(int(c)**(-0.5)))
         ops.softmax_rows_(s)
         o = torch.empty((n_img, n, c), device=x.device, dtype=torch.float32)
         ops.bgemm(s, q3[:, :, 2 * c:], o, b_trans=True)
-        return ops.gemm(o.view(n_img * n, c), P[f'{pfx}.proj.w'], bias=P[f'{pfx}.proj.b'], residual=x,
-                        w_split=self._ws(f'{pfx}.proj.w', n), rows_per_img=n)
+        return self._conv1x1(o.view(n_img * n, c), f'{pfx}.proj', n, residual=x)
 
     def _mid(self, h, n_img, hh, ww):
         nm = self.name
@@ -73,12 +89,13 @@ class VQGANStack:
         h = self.attnblock(h, f'{nm}.mid.attn_1', n_img, hh * ww)
         return self.resblock(h, f'{nm}.mid.block_2', n_img, hh, ww)
 
-    def _conv(self, x, pfx, n_img, h, w, mode='same', **kw):
-        P = self.P
-        cin = P[f'{pfx}.w'].shape[1] // 9
-        hw_out = h * w * (4 if mode == 'up' else 1)
-        return ops.conv3x3(x, P[f'{pfx}.w'], n_img, h, w, cin, bias=P[f'{pfx}.b'], mode=mode,
-                           w_split=self._ws(f'{pfx}.w', hw_out, mode), **kw)
+    def _conv(self, x, pfx, n_img, h, w, mode='same', residual=None):
+        """3x3 convolution without a norm in front (conv_in, Upsample / Downsample convs)."""
+        if mode == 'down':
+            P = self.P
+            return ops.conv3x3(x, P[f'{pfx}.w'], n_img, h, w, P[f'{pfx}.w'].shape[1] // 9, bias=P[f'{pfx}.b'],
+                               mode=mode, residual=residual)
+        return self._norm_conv3x3(x, None, pfx, n_img, h, w, mode=mode, residual=residual)
 
     def encode(self, x, n_img, h, w):
         """Encoder.forward (vqgan_arch.py:892-919); x rows [n_img*h*w, Cin_pad]."""
@@ -94,8 +111,7 @@ class VQGANStack:
                 t = self._conv(t, f"{nm}.down.{lv['level']}.downsample", n_img, h, w, mode='down')
                 h, w = h // 2, w // 2
         t = self._mid(t, n_img, h, w)
-        sc, sh = self._gn(t, f'{nm}.norm_out', n_img, h * w)
-        return self._conv(t, f'{nm}.conv_out', n_img, h, w, pro=(sc, sh, PRO_SWISH)), h, w
+        return self._norm_conv3x3(t, f'{nm}.norm_out', f'{nm}.conv_out', n_img, h, w), h, w
 
     def decode(self, z, n_img, h, w, bot_h=None, upscale=False):
         """Decoder.forward (vqgan_arch.py:1000-1033).  `bot_h` is added in the
@@ -120,8 +136,7 @@ class VQGANStack:
                 h, w = 2 * h, 2 * w
             elif lv['level'] == 4 and bot_h is not None:
                 t = t + bot_h
-        sc, sh = self._gn(t, f'{nm}.norm_out', n_img, h * w)
-        return self._conv(t, f'{nm}.conv_out', n_img, h, w, pro=(sc, sh, PRO_SWISH)), h, w
+        return self._norm_conv3x3(t, f'{nm}.norm_out', f'{nm}.conv_out', n_img, h, w), h, w
 
     def decode_res(self, z, n_img, h, w, upscale=False):
         """DecoderRes.forward (vqgan_arch.py:1136-1151)."""

@@ -98,14 +98,12 @@ def _launch_gemm(g, what):
 
 
 def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=None,
-         b_trans=False, w_split=None, rows_per_img=0):
+         b_trans=False):
     """out[M,N] = act(alpha * pro(a)[M,K] @ w[N,K]^T + bias) + residual.
 
     a, w, out, residual: 2-D views with unit inner stride (row stride free).
     pro = (scale[n_img,K], shift[n_img,K], rows_per_img, pro_act).
-    b_trans: w is given as [K,N].
-    w_split (split rows of w) + rows_per_img: the product runs on the fp16 matrix cores
-    (t2h_conv_split_f32, 1x1 mode) instead of the fp32 ones."""
+    b_trans: w is given as [K,N]."""
     _chk_f32(a, w, out, bias, residual)
     M, K = a.shape
     N = w.shape[1] if b_trans else w.shape[0]
@@ -126,12 +124,6 @@ def gemm(a, w, out=None, bias=None, residual=None, act=ACT_NONE, alpha=1.0, pro=
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_rows, g.pro_ld, g.pro_act = rows, sc.shape[1], pact
     g.batch = 1
-    if w_split is not None:
-        assert not b_trans and alpha == 1.0 and act in (ACT_NONE, ACT_RELU)
-        g.B = w_split.data_ptr()
-        g.pro_rows = g.pro_rows or rows_per_img
-        _launch_conv_split(g, 2.0 * M * N * K)
-        return out
     _launch_gemm(g, 't2h_gemm_f32')
     return out
 
@@ -156,6 +148,47 @@ def conv_split_ok(n_pix_per_img, mode='same', act=ACT_NONE):
     return mode in ('same', 'up') and n_pix_per_img % 128 == 0 and act in (ACT_NONE, ACT_RELU)
 
 
+def gn_apply_split(x, scale=None, shift=None, rows_per_img=0, act=PRO_NONE, out=None):
+    """fp32 pixel rows x [rows, C] -> split rows of act(x * scale[img] + shift[img]) (GroupNorm apply
+    + swish in one pass; scale None = plain split): the activation operand of conv_split."""
+    _chk_f32(x, scale, shift)
+    rows, C = x.shape
+    if out is None:
+        out = split_rows_empty(rows, C, x.device)
+    check(_lib.load().t2h_gn_apply_split_f32(_p(x), _rows(x), _p(scale), _p(shift),
+                                             scale.shape[1] if scale is not None else 0, _p(out), rows,
+                                             rows_per_img, C, act, _stream()), 't2h_gn_apply_split_f32')
+    return out
+
+
+def conv_split(xs, w_split, n_img, hin, win, cin, cout, taps=9, out=None, bias=None, residual=None,
+               act=ACT_NONE, mode='same', res_pre=False):
+    """Stride-1 convolution (taps 9: 3x3 'same' or, mode 'up', 3x3 after nearest x2; taps 1: 1x1) of
+    split-row activations xs [n_img*hin*win, cin/32, 2, 32] with split-row weights
+    w_split [cout, taps*cin/32, 2, 32] on the fp16 matrix cores; fp32 rows out [M, cout]."""
+    _chk_f32(out, bias, residual)
+    assert mode in ('same', 'up') and taps in (1, 9)
+    ups = 1 if mode == 'up' else 0
+    hout, wout = hin << ups, win << ups
+    M = n_img * hout * wout
+    assert xs.numel() == n_img * hin * win * cin * 2 and w_split.numel() == cout * taps * cin * 2, \
+        (tuple(xs.shape), tuple(w_split.shape), n_img, hin, win, cin, cout, taps)
+    if out is None:
+        out = torch.empty((M, cout), device=xs.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.A, g.B, g.C = xs.data_ptr(), w_split.data_ptr(), out.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.residual = residual.data_ptr() if residual is not None else None
+    g.M, g.N, g.K = M, cout, taps * cin
+    g.lda, g.ldb, g.ldc = 0, 0, _rows(out)
+    g.ldr = _rows(residual) if residual is not None else 0
+    g.a_mode, g.epi_act, g.alpha, g.res_pre = 1, act, 1.0, int(res_pre)
+    g.Hin, g.Win, g.Cin, g.Hout, g.Wout = hin, win, cin, hout, wout
+    g.stride, g.pad, g.ups, g.batch = 1, (1 if taps == 9 else 0), ups, 1
+    _launch_conv_split(g, 2.0 * M * cout * taps * cin)
+    return out
+
+
 def bgemm(a, w, out, alpha=1.0, b_trans=False):
     """Batched: a [b,M,K], w [b,N,K] (or [b,K,N] if b_trans), out [b,M,N]; 3-D
     views with unit inner stride (batch / row strides free)."""
@@ -174,7 +207,7 @@ def bgemm(a, w, out, alpha=1.0, b_trans=False):
 
 
 def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=ACT_NONE,
-            pro=None, mode='same', res_pre=False, w_split=None):
+            pro=None, mode='same', res_pre=False):
     """3x3 convolution of an NHWC image held as pixel rows x [n_img*hin*win, >=cin]
     with packed weights w [Cout, 9*cin] ([tap][cin] order).
 
@@ -208,10 +241,6 @@ def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=
         _chk_f32(sc, sh)
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_ld, g.pro_act = sc.shape[1], pact
-    if w_split is not None:  # split rows of w: fp16 matrix cores, fp32-class accuracy
-        g.B = w_split.data_ptr()
-        _launch_conv_split(g, 2.0 * M * N * 9 * cin)
-        return out
     _launch_gemm(g, 't2h_gemm_f32(conv)')
     return out
 
