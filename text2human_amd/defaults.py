@@ -83,6 +83,48 @@ def sample_from_pose(ckpt_dir='./pretrained_models'):
     return o
 
 
+def index_pred_net(ckpt_dir='./pretrained_models'):
+    """Network keys of the reference's configs/index_pred_net.yml (model_type
+    VQGANTextureAwareSpatialHierarchyInferenceModel): ONLY the two VAE checkpoints."""
+    o = OrderedDict()
+    o['name'] = 'index_prediction_network'
+    o['model_type'] = 'VQGANTextureAwareSpatialHierarchyInferenceModel'
+    o.update(embed_dim=256, n_embed=1024, codebook_spatial_size=2)
+    o.update(bot_n_embed=512, bot_double_z=False, bot_z_channels=256, bot_resolution=512, bot_in_channels=3,
+             bot_out_ch=3, bot_ch=128, bot_ch_mult=[1, 1, 2, 4], bot_num_res_blocks=2, bot_attn_resolutions=[64],
+             bot_dropout=0.0, bot_vae_path=f'{ckpt_dir}/vqvae_bottom.pth')
+    o.update(top_double_z=False, top_z_channels=256, top_resolution=512, top_in_channels=3, top_out_ch=3,
+             top_ch=128, top_ch_mult=[1, 1, 2, 2, 4], top_num_res_blocks=2, top_attn_resolutions=[32],
+             top_dropout=0.0, top_vae_path=f'{ckpt_dir}/vqvae_top.pth')
+    o.update(encoder_in_channels=256, fc_in_channels=64, fc_in_index=4, fc_channels=64, fc_num_convs=1,
+             fc_concat_input=False, fc_dropout_ratio=0.1, fc_num_classes=512, fc_align_corners=False)
+    o['manual_seed'] = 2021
+    return o
+
+
+def sampler(ckpt_dir='./pretrained_models'):
+    """Network keys of the reference's configs/sampler.yml (model_type TransformerTextureAwareModel):
+    img_ae_path / segm_ae_path + img_* / segm_* architecture keys.  `pretrained_sampler` (not in the
+    reference YAML, which TRAINS the sampler) names the checkpoint train_sampler.py wrote, for the
+    forward-only class of this package."""
+    o = OrderedDict()
+    o['name'] = 'sampler'
+    o['model_type'] = 'TransformerTextureAwareModel'
+    o.update(img_ae_path=f'{ckpt_dir}/vqvae_top.pth', segm_ae_path=f'{ckpt_dir}/parsing_token.pth')
+    o.update(img_embed_dim=256, img_n_embed=1024, img_double_z=False, img_z_channels=256, img_resolution=512,
+             img_in_channels=3, img_out_ch=3, img_ch=128, img_ch_mult=[1, 1, 2, 2, 4], img_num_res_blocks=2,
+             img_attn_resolutions=[32], img_dropout=0.0)
+    o.update(segm_double_z=False, segm_z_channels=32, segm_resolution=512, segm_in_channels=24, segm_out_ch=24,
+             segm_ch=64, segm_ch_mult=[1, 1, 2, 2, 4], segm_num_res_blocks=1, segm_attn_resolutions=[16],
+             segm_dropout=0.0, segm_num_segm_classes=24, segm_n_embed=1024, segm_embed_dim=32)
+    o.update(codebook_size=18432, segm_codebook_size=1024, texture_codebook_size=18, bert_n_emb=512,
+             bert_n_layers=24, bert_n_head=8, block_size=512, latent_shape=[32, 16], embd_pdrop=0.0,
+             resid_pdrop=0.0, attn_pdrop=0.0, num_head=18, loss_type='reweighted_elbo', mask_schedule='random',
+             sample_steps=256, pretrained_sampler=f'{ckpt_dir}/sampler.pth')
+    o['manual_seed'] = 2021
+    return o
+
+
 def write_yaml(opt, path):
     with open(path, 'w') as f:
         yaml.safe_dump(dict(opt), f, sort_keys=False)

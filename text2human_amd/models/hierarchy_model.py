@@ -18,7 +18,7 @@ class VQGANTextureAwareSpatialHierarchyInferenceModel():
         _lib.load()
         self.device = torch.device('cuda', torch.cuda.current_device())
         self.is_train = False
-        sds = state_dicts if state_dicts is not None else weights.load_checkpoints(opt, encode=True)
+        sds = state_dicts if state_dicts is not None else weights.load_hierarchy_checkpoints(opt)
         P = weights.Params(self.device)
         self.P = P
         self.top_encoder = engine.VQGANStack(P, 'tenc', weights.pack_vqgan(P, sds['top_encoder'], 'tenc'))
@@ -32,7 +32,7 @@ class VQGANTextureAwareSpatialHierarchyInferenceModel():
                         ('bot.qc', 'bot_quant_conv'), ('bot.pq', 'bot_post_quant_conv')):
             P.put(f'{nm}.w', weights.pack_conv1x1(sds[key]['weight']))
             P.put(f'{nm}.b', sds[key]['bias'])
-        self.spatial = opt['codebook_spatial_size']
+        self.spatial = opt['codebook_spatial_size'] or opt['bot_codebook_spatial_size']
 
     # ------------------------------------------------------------ helpers
     def _tex_tokens(self, mask, h, w):

@@ -20,7 +20,7 @@ class TransformerTextureAwareModel():
         _lib.load()
         self.device = torch.device('cuda', torch.cuda.current_device())
         self.is_train = False
-        sds = state_dicts if state_dicts is not None else weights.load_checkpoints(opt, encode=True)
+        sds = state_dicts if state_dicts is not None else weights.load_transformer_checkpoints(opt)
         P = weights.Params(self.device)
         self.P = P
         self.img_encoder = engine.VQGANStack(P, 'ienc', weights.pack_vqgan(P, sds['top_encoder'], 'ienc'))

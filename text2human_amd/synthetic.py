@@ -340,12 +340,109 @@ def module_schemas(opt, encode=False):
     return s
 
 
+def _one_by_one(cout, cin):
+    s = OrderedDict()
+    _conv(s, '', cout, cin, 1)
+    return OrderedDict((n.lstrip('.'), v) for n, v in s.items())
+
+
+def hierarchy_schemas(opt):
+    """state_dict schemas of VQGANTextureAwareSpatialHierarchyInferenceModel from the key set of
+    the reference's configs/index_pred_net.yml (hierarchy_inference_model.py:28-129): the two VAEs only."""
+    s = OrderedDict()
+    sp = opt['codebook_spatial_size'] or opt['bot_codebook_spatial_size']
+    s['top_encoder'] = encoder_schema(opt['top_ch'], opt['top_ch_mult'], opt['top_num_res_blocks'],
+                                      opt['top_attn_resolutions'], opt['top_in_channels'], opt['top_resolution'],
+                                      opt['top_z_channels'], opt['top_double_z'])
+    s['decoder'] = decoder_schema(opt['top_ch'], opt['top_ch_mult'], opt['top_num_res_blocks'],
+                                  opt['top_attn_resolutions'], opt['top_resolution'], opt['top_z_channels'],
+                                  opt['top_out_ch'])
+    s['top_quantize'] = codebook_list_schema(opt['n_embed'], opt['embed_dim'], spread=1.0)
+    s['top_quant_conv'] = _one_by_one(opt['embed_dim'], opt['top_z_channels'])
+    s['top_post_quant_conv'] = _one_by_one(opt['top_z_channels'], opt['embed_dim'])
+    s['bot_encoder'] = encoder_schema(opt['bot_ch'], opt['bot_ch_mult'], opt['bot_num_res_blocks'],
+                                      opt['bot_attn_resolutions'], opt['bot_in_channels'], opt['bot_resolution'],
+                                      opt['bot_z_channels'], opt['bot_double_z'])
+    s['bot_decoder_res'] = decoder_res_schema(opt['bot_ch'], opt['bot_ch_mult'], opt['bot_z_channels'])
+    s['bot_quantize'] = codebook_list_schema(opt['bot_n_embed'], opt['embed_dim'] * sp * sp, spread=1.0)
+    s['bot_quant_conv'] = _one_by_one(opt['embed_dim'], opt['bot_z_channels'])
+    s['bot_post_quant_conv'] = _one_by_one(opt['bot_z_channels'], opt['embed_dim'])
+    return s
+
+
+def transformer_model_schemas(opt):
+    """state_dict schemas of TransformerTextureAwareModel from the key set of the reference's
+    configs/sampler.yml (transformer_model.py:27-99): image VAE (img_*), parsing tokenizer (segm_*),
+    the sampler."""
+    s = OrderedDict()
+    s['img_encoder'] = encoder_schema(opt['img_ch'], opt['img_ch_mult'], opt['img_num_res_blocks'],
+                                      opt['img_attn_resolutions'], opt['img_in_channels'], opt['img_resolution'],
+                                      opt['img_z_channels'], opt['img_double_z'])
+    s['img_decoder'] = decoder_schema(opt['img_ch'], opt['img_ch_mult'], opt['img_num_res_blocks'],
+                                      opt['img_attn_resolutions'], opt['img_resolution'], opt['img_z_channels'],
+                                      opt['img_out_ch'])
+    s['img_quantizer'] = codebook_list_schema(opt['img_n_embed'], opt['img_embed_dim'], spread=1.0)
+    s['img_quant_conv'] = _one_by_one(opt['img_embed_dim'], opt['img_z_channels'])
+    s['img_post_quant_conv'] = _one_by_one(opt['img_z_channels'], opt['img_embed_dim'])
+    s['segm_encoder'] = encoder_schema(opt['segm_ch'], opt['segm_ch_mult'], opt['segm_num_res_blocks'],
+                                       opt['segm_attn_resolutions'], opt['segm_in_channels'], opt['segm_resolution'],
+                                       opt['segm_z_channels'], opt['segm_double_z'])
+    s['segm_quantizer'] = OrderedDict([('embedding.weight', ((opt['segm_n_embed'], opt['segm_embed_dim']),
+                                                            ('uniform', 1.0)))])
+    s['segm_quant_conv'] = _one_by_one(opt['segm_embed_dim'], opt['segm_z_channels'])
+    s['sampler'] = transformer_schema(opt['codebook_size'], opt['segm_codebook_size'], opt['texture_codebook_size'],
+                                      opt['bert_n_emb'], opt['bert_n_layers'], opt['block_size'], opt['num_head'])
+    return s
+
+
 _SEEDS = dict(decoder=11, top_quantize=12, top_post_quant_conv=13,
               bot_decoder_res=21, bot_quantize=22, bot_post_quant_conv=23,
               segm_encoder=31, segm_quantizer=32, segm_quant_conv=33,
               guidance_encoder=41, index_decoder=42, sampler=51,
               shape_embedder=61, shape_encoder=62, shape_decoder=63,
-              top_encoder=71, top_quant_conv=72, bot_encoder=73, bot_quant_conv=74)
+              top_encoder=71, top_quant_conv=72, bot_encoder=73, bot_quant_conv=74,
+              img_encoder=71, img_decoder=11, img_quantizer=12, img_quant_conv=72, img_post_quant_conv=13)
+
+
+def write_hierarchy_checkpoints(opt, out_dir, seed=1234):
+    """vqvae_top.pth / vqvae_bottom.pth as the reference's train_vqvae_* scripts leave them, for a
+    configs/index_pred_net.yml-style `opt`; returns the opt copy pointing at them."""
+    os.makedirs(out_dir, exist_ok=True)
+    sds = {n: fill(sc, seed * 1000 + _SEEDS[n]) for n, sc in hierarchy_schemas(opt).items()}
+    files = {
+        'top_vae_path': ('vqvae_top.pth', dict(encoder=sds['top_encoder'], decoder=sds['decoder'],
+                                               quantize=sds['top_quantize'], quant_conv=sds['top_quant_conv'],
+                                               post_quant_conv=sds['top_post_quant_conv'])),
+        'bot_vae_path': ('vqvae_bottom.pth', dict(bot_encoder=sds['bot_encoder'],
+                                                  bot_decoder_res=sds['bot_decoder_res'], decoder=sds['decoder'],
+                                                  bot_quantize=sds['bot_quantize'],
+                                                  bot_quant_conv=sds['bot_quant_conv'],
+                                                  bot_post_quant_conv=sds['bot_post_quant_conv'])),
+    }
+    new_opt = type(opt)(opt)
+    for key, (fname, payload) in files.items():
+        torch.save(payload, os.path.join(out_dir, fname))
+        new_opt[key] = os.path.join(out_dir, fname)
+    return new_opt, sds
+
+
+def write_transformer_checkpoints(opt, out_dir, seed=1234):
+    """vqvae_top.pth / parsing_token.pth / sampler.pth for a configs/sampler.yml-style `opt`."""
+    os.makedirs(out_dir, exist_ok=True)
+    sds = {n: fill(sc, seed * 1000 + _SEEDS[n]) for n, sc in transformer_model_schemas(opt).items()}
+    files = {
+        'img_ae_path': ('vqvae_top.pth', dict(encoder=sds['img_encoder'], decoder=sds['img_decoder'],
+                                              quantize=sds['img_quantizer'], quant_conv=sds['img_quant_conv'],
+                                              post_quant_conv=sds['img_post_quant_conv'])),
+        'segm_ae_path': ('parsing_token.pth', dict(encoder=sds['segm_encoder'], quantize=sds['segm_quantizer'],
+                                                   quant_conv=sds['segm_quant_conv'])),
+        'pretrained_sampler': ('sampler.pth', sds['sampler']),
+    }
+    new_opt = type(opt)(opt)
+    for key, (fname, payload) in files.items():
+        torch.save(payload, os.path.join(out_dir, fname))
+        new_opt[key] = os.path.join(out_dir, fname)
+    return new_opt, sds
 
 
 def make_state_dicts(opt, seed=1234, head_scale=1.0, argmax_scale=1.0, encode=False):

@@ -282,6 +282,49 @@ def stack_codebooks(sd):
     return torch.stack([sd[f'embedding_list.{i}.weight'] for i in range(n)], 0)
 
 
+def _load(path, what):
+    if not path:
+        raise KeyError(f'the option file names no checkpoint for {what}')
+    return torch.load(path, map_location='cpu', weights_only=False)
+
+
+def load_hierarchy_checkpoints(opt):
+    """What VQGANTextureAwareSpatialHierarchyInferenceModel loads (hierarchy_inference_model.py:
+    131-161) from the key set of the reference's configs/index_pred_net.yml: top_vae_path and
+    bot_vae_path ONLY (the bottom checkpoint's `decoder` overrides the top one's, :155), every
+    state_dict validated strictly.  Module names as engine / models use them."""
+    sc = synthetic.hierarchy_schemas(opt)
+    top, bot = _load(opt['top_vae_path'], 'top_vae_path'), _load(opt['bot_vae_path'], 'bot_vae_path')
+    check_state_dict(top['decoder'], sc['decoder'], 'Decoder (top_vae_path)')  # loaded first, then overridden
+    sds = dict(top_encoder=top['encoder'], decoder=bot['decoder'], top_quantize=top['quantize'],
+               top_quant_conv=top['quant_conv'], top_post_quant_conv=top['post_quant_conv'],
+               bot_encoder=bot['bot_encoder'], bot_decoder_res=bot['bot_decoder_res'],
+               bot_quantize=bot['bot_quantize'], bot_quant_conv=bot['bot_quant_conv'],
+               bot_post_quant_conv=bot['bot_post_quant_conv'])
+    for name, sd in sds.items():
+        check_state_dict(sd, sc[name], name)
+    return sds
+
+
+def load_transformer_checkpoints(opt):
+    """What TransformerTextureAwareModel loads (transformer_model.py:107-139) from the key set of the
+    reference's configs/sampler.yml: img_ae_path {encoder, decoder, quantize, quant_conv,
+    post_quant_conv} and segm_ae_path {encoder, quantize, quant_conv}, strictly validated; plus the
+    sampler itself from `pretrained_sampler` (the reference trains it; this package's class is
+    forward-only).  Returned under the module names the model packs (top_* = the image VAE)."""
+    sc = synthetic.transformer_model_schemas(opt)
+    img, seg = _load(opt['img_ae_path'], 'img_ae_path'), _load(opt['segm_ae_path'], 'segm_ae_path')
+    smp = _load(opt['pretrained_sampler'], 'pretrained_sampler (the checkpoint train_sampler.py wrote)')
+    for name, sd in (('img_encoder', img['encoder']), ('img_decoder', img['decoder']),
+                     ('img_quantizer', img['quantize']), ('img_quant_conv', img['quant_conv']),
+                     ('img_post_quant_conv', img['post_quant_conv']), ('segm_encoder', seg['encoder']),
+                     ('segm_quantizer', seg['quantize']), ('segm_quant_conv', seg['quant_conv']), ('sampler', smp)):
+        check_state_dict(sd, sc[name], name)
+    return dict(top_encoder=img['encoder'], top_quantize=img['quantize'], top_quant_conv=img['quant_conv'],
+                segm_encoder=seg['encoder'], segm_quantizer=seg['quantize'], segm_quant_conv=seg['quant_conv'],
+                sampler=smp)
+
+
 def load_checkpoints(opt, map_location='cpu', encode=False):
     """Reads the `.pth` files named by the YAML exactly like
     BaseSampleModel.load_* (models/sample_model.py:124-181,397-410), including
