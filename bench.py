@@ -396,7 +396,8 @@ def main(argv=None):
         'vs_baseline': None,
         'dtype': ('stub' if stub else 'f32' if not split_on else
                   'f32 (sampler Linears + attention as 2xfp16-split MFMA, 3 partial products, fp32 accumulate: '
-                  '22-bit operands, fp32-class accuracy -- see "parity"; everything else exact-fp32 MFMA)'),
+                  '22-bit operands, fp32-class accuracy -- see "parity"; decoder convolutions likewise '
+                  '(t2h_conv_split_f32); tokenizer, index-prediction UNet, parsing generator exact-fp32 MFMA)'),
         'data': 'synthetic',
         'config': {
             'workload': (f'{wl["desc"]}, batch={batch_per_gpu}/GPU, {args.sample_steps} sampling steps '
@@ -456,12 +457,17 @@ def main(argv=None):
             t = stage_ms['refine_decode'] * 1e-3
             fl = ((GFLOP_IMAGE['decode_hires'] if upscale else GFLOP_IMAGE['decode']) + GFLOP_IMAGE['refine']) * b * 1e9
             by = DECODE_BYTES_IMAGE['hires' if upscale else 'parsing'] * b + DECODE_WEIGHT_BYTES
+            split_conv = os.environ.get('T2H_SPLIT_CONV', '1') != '0'
             st['refine_decode'].update(
                 ms_per_image=1e3 * t / b, tflops=fl / t / 1e12,
                 compute_frac_of_fp32_mfma_peak=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                compute_frac_of_16bit_mfma_peak=(3.0 if split_conv else 1.0) * fl / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                 algorithmic_hbm_bytes=by, hbm_frac=by / t / (HBM_PEAK_TBS * 1e12),
-                note='SURVEY.md 8(d) algorithmic FLOPs / bytes (flash-style attention, fused norms); '
-                     'the stage is matrix-bound in fp32: at 100% of the fp32 MFMA peak its HBM fraction is 6.5%')
+                convs=('2xfp16-split MFMA, three products (t2h_conv_split_f32): executed = 3 x the reference FLOPs'
+                       if split_conv else 'exact-fp32 MFMA'),
+                note='SURVEY.md 8(d) algorithmic FLOPs / bytes (flash-style attention, fused norms).  The stage '
+                     'is matrix-bound: at 100% of the fp32 MFMA peak its HBM fraction would be 6.5%, at 100% of '
+                     'the three-product fp16 rate 35%')
         if 'pose_front_end' in st:
             t = stage_ms['pose_front_end'] * 1e-3
             fl = GFLOP_IMAGE['pose'] * b * 1e9

@@ -43,7 +43,15 @@ def _compile(src):
     dig = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    subprocess.run([hipcc, *FLAGS, '-c', path, '-o', obj], check=True)
+    # the per-kernel resource report (registers, spills, scratch, LDS) is kept next to the object:
+    # tests/test_build_resources.py fails the build check if a hot kernel needs scratch memory
+    r = subprocess.run([hipcc, *FLAGS, '-Rpass-analysis=kernel-resource-usage', '-c', path, '-o', obj],
+                       stderr=subprocess.PIPE, text=True)
+    with open(obj + '.resources.log', 'w') as f:
+        f.write(r.stderr)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr)
+        raise subprocess.CalledProcessError(r.returncode, r.args)
     with open(stamp, 'w') as f:
         f.write(dig)
     return obj, True

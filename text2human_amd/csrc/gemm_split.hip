@@ -176,6 +176,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
+  {  // (scope: the staging registers and addresses are dead before the epilogue -- without it the
+     // register allocator of ROCm 7.2 spilled 423 registers in the 256x128 instantiation)
   // ---- per-thread staging slots (fixed for the whole kernel).  Rows beyond M / N are
   // loaded from a clamped (valid) address and NOT masked: an output element depends only
   // on its own A row and B row, and rows / columns beyond the problem are never stored.
@@ -283,16 +285,18 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     }
     __syncthreads();
   };
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
+  // (no third, peeled copy of `step` for an odd tile count: the register allocator spilled 423
+  // registers in it, and a kernel that needs scratch pays for it at every launch -- 45 instead of
+  // 33 us on the q|k|v / fc1 shapes -- whether or not the spilling path runs)
+  for (int kt = 0; kt < nk; kt += 2) {
     step(kt, set1{});
-    step(kt + 1, set0{});
+    if (kt + 1 < nk) step(kt + 1, set0{});
   }
-  if (nk & 1) step(nk - 1, set1{});
 #pragma unroll
   for (int S = 0; S < 2; ++S)
 #pragma unroll
     for (int i = 0; i < L; ++i) wait_vmcnt16<0>(rg[S][i]);
+  }
   G1_MARK(2);
   // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (r&3) +
   // 8*(r>>2) + 4*(lane>>5)) are transposed through the (now idle) LDS so that every
