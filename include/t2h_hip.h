@@ -225,6 +225,8 @@ typedef struct t2h_sample_heads_args {
   int64_t* out_idx;         /* [n_heads][n] */
   float temp;
   int32_t n_rows, n, C, n_class, n_heads;
+  float* logits_ws;         /* optional scratch [n_rows][n_class]: the head GEMV of a row is then spread
+                               over 8 workgroups and the race runs in a second launch (same results) */
 } t2h_sample_heads_args;
 int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream);
 

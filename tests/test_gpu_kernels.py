@@ -270,9 +270,17 @@ def test_sample_heads_one_launch_equals_per_head_launches():
         ops.sample_head(hidden, g, b, w[h], expo[h], chd, texd, h, 1.0, x_a, out_a[h])
     x_b, out_b = torch.full_like(x_a, 18432), torch.full_like(out_a, -1)
     rows = torch.nonzero(changes).flatten().flip(0).to(torch.int32).to(DEV)   # any order
-    ops.sample_heads(hidden, g, b, w, expo, rows, rows.numel(), texd, 1.0, x_b, out_b)
+    ops.sample_heads(hidden, g, b, w, expo, rows, rows.numel(), texd, 1.0, x_b, out_b, split=False)
     assert (out_a >= 0).sum() == int(changes.sum())
     assert torch.equal(x_a, x_b) and torch.equal(out_a, out_b)
+    # the default two-launch form (8 workgroups per row + race kernel) gives the same bits
+    x_c, out_c = torch.full_like(x_a, 18432), torch.full_like(out_a, -1)
+    ops.sample_heads(hidden, g, b, w, expo, rows, rows.numel(), texd, 0.7, x_c, out_c)
+    x_d, out_d = torch.full_like(x_a, 18432), torch.full_like(out_a, -1)
+    ops.sample_heads(hidden, g, b, w, expo, rows, rows.numel(), texd, 0.7, x_d, out_d, split=False)
+    assert torch.equal(x_c, x_d) and torch.equal(out_c, out_d)
+    ops.sample_heads(hidden, g, b, w, expo, rows, rows.numel(), texd, 1.0, x_c, out_c)
+    assert torch.equal(x_a, x_c) and torch.equal(out_a, out_c)
 
 
 # ------------------------------------------------------------------ quantizer pieces

@@ -53,6 +53,7 @@ class SampleHeadsArgs(ctypes.Structure):
         ('hidden', c_vp), ('lnf_gamma', c_vp), ('lnf_beta', c_vp), ('w_heads', c_vp),
         ('expo', c_vp * MAX_HEADS), ('rows', c_vp), ('tex', c_vp), ('x_t', c_vp), ('out_idx', c_vp),
         ('temp', c_f32), ('n_rows', c_i32), ('n', c_i32), ('C', c_i32), ('n_class', c_i32), ('n_heads', c_i32),
+        ('logits_ws', c_vp),
     ]
 
 

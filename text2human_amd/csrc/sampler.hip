@@ -278,6 +278,127 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
   if (tid == 0) out[b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- two-launch form of the same tail (t2h_sample_heads with a logits workspace).  One workgroup
+// per changed row streams 2 MB of head weights by itself (~50 us per step with ~16 rows on 16 CUs);
+// here SL_SPLIT workgroups per row take n_class / SL_SPLIT classes each (LN_f recomputed per
+// workgroup: 2 KB), then a second launch does max / exponential race over the row's logits.
+// Every logit is the same per-lane fma chain + wave butterfly as in sample_row, so the results are
+// bit-identical to the one-launch form.
+constexpr int SL_SPLIT = 8, SL_THREADS = 256;
+
+template <int C>
+__global__ __launch_bounds__(SL_THREADS) void sample_logits_kernel(const t2h_sample_heads_args a, float* __restrict__ ws) {
+  constexpr int VPL = C / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = blockIdx.x / SL_SPLIT, part = blockIdx.x - slot * SL_SPLIT;
+  const int row = a.rows[slot];
+  const int head = (int)a.tex[row];
+  const float* xr = a.hidden + (int64_t)row * C;
+  f32x4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      q = fmaf(d, d, q);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(a.lnf_gamma + i * 256 + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(a.lnf_beta + i * 256 + lane * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+  }
+  const float inv_temp = 1.0f / a.temp;
+  const float* w = a.w_heads + (int64_t)head * a.n_class * C;
+  const int per = (a.n_class + SL_SPLIT - 1) / SL_SPLIT;
+  const int j_end = min(a.n_class, (part + 1) * per);
+  constexpr int NW = SL_THREADS / 64;
+  for (int j0 = part * per + wave * 4; j0 < j_end; j0 += NW * 4) {
+    float acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, a.n_class - 1);
+      const float* wr = w + (int64_t)j * C;
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + i * 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t = fmaf(ww[e], v[i][e], t);
+      }
+      acc[u] = t;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float r = wave_sum(acc[u]);
+      if (lane == 0 && j0 + u < j_end) ws[(int64_t)slot * a.n_class + j0 + u] = r * inv_temp;
+    }
+  }
+}
+
+__global__ __launch_bounds__(SH_THREADS) void sample_pick_kernel(const t2h_sample_heads_args a, const float* __restrict__ ws) {
+  __shared__ float red[2 * (SH_THREADS / 64)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = SH_THREADS / 64;
+  const int slot = blockIdx.x, row = a.rows[slot];
+  const int head = (int)a.tex[row];
+  const float* lg = ws + (int64_t)slot * a.n_class;
+  float mx = -INFINITY;
+  for (int j = tid; j < a.n_class; j += SH_THREADS) mx = fmaxf(mx, lg[j]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) mx = fmaxf(mx, red[k]);
+  const float* er = a.expo[head] + (int64_t)row * a.n_class;
+  float best = -1.f;
+  int best_j = 0x7fffffff;
+  for (int j = tid; j < a.n_class; j += SH_THREADS) {
+    const float sc = expf(lg[j] - mx) / er[j];
+    if (sc > best) {
+      best = sc;
+      best_j = j;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oj = __shfl_xor(best_j, o, 64);
+    if (ob > best || (ob == best && oj < best_j)) {
+      best = ob;
+      best_j = oj;
+    }
+  }
+  __syncthreads();
+  int* redj = reinterpret_cast<int*>(red + NW);
+  if (lane == 0) {
+    red[wave] = best;
+    redj[wave] = best_j;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < NW; ++k)
+      if (red[k] > best || (red[k] == best && redj[k] < best_j)) {
+        best = red[k];
+        best_j = redj[k];
+      }
+    if (best_j >= a.n_class) best_j = 0;  // all-NaN scores: see sample_row
+    a.x_t[row] = (int64_t)best_j + (int64_t)a.n_class * head;
+    a.out_idx[(int64_t)head * a.n + row] = best_j;
+  }
+}
+
 // All heads in one launch: one workgroup per CHANGED token (compact list from
 // unmask_step), which picks the head / noise tensor of its own texture.
 template <int C>
@@ -346,6 +467,13 @@ extern "C" int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream)
               "t2h_sample_heads: bad arguments");
   T2H_REQUIRE(a.C == 512, "t2h_sample_heads: C=%d unsupported (512)", a.C);
   if (a.n_rows == 0) return T2H_OK;
+  if (a.logits_ws) {  // two launches, SL_SPLIT workgroups per row stream the head weights
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sample_logits_kernel<512>, dim3(a.n_rows * SL_SPLIT), dim3(SL_THREADS), 0, s, a, a.logits_ws);
+    hipLaunchKernelGGL(sample_pick_kernel, dim3(a.n_rows), dim3(SH_THREADS), 0, s, a, a.logits_ws);
+    T2H_CHECK_LAUNCH("t2h_sample_heads");
+    return T2H_OK;
+  }
   const size_t lds = (size_t)(a.n_class + 2 * (SH_THREADS / 64)) * sizeof(float);
   hipLaunchKernelGGL(sample_heads_kernel<512>, dim3(a.n_rows), dim3(SH_THREADS), lds,
                      static_cast<hipStream_t>(stream), a);

@@ -444,7 +444,7 @@ def unmask_step(rand, t, unmasked, changes, tex, head_count, changed_rows=None, 
           't2h_unmask_step')
 
 
-def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex, temp, x_t, out_idx):
+def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex, temp, x_t, out_idx, split=True):
     """All heads in one launch: `rows` (int32, first n_rows valid) are the changed token
     rows, expo_by_head {head: [n, n_class] Exp(1) draw}, w_heads [n_heads, n_class, C],
     out_idx [n_heads, n]."""
@@ -460,6 +460,9 @@ def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex,
         a.expo[h] = e.data_ptr()
     a.rows, a.tex, a.x_t, a.out_idx = rows.data_ptr(), tex.data_ptr(), x_t.data_ptr(), out_idx.data_ptr()
     a.temp, a.n_rows, a.n, a.C, a.n_class, a.n_heads = float(temp), int(n_rows), n, C, n_class, n_heads
+    if split and n_rows > 0:  # logits scratch: 8 workgroups per row share the head weight stream
+        ws = torch.empty((int(n_rows), n_class), device=hidden.device, dtype=torch.float32)
+        a.logits_ws = ws.data_ptr()
     check(_lib.load().t2h_sample_heads(ctypes.byref(a), _stream()), 't2h_sample_heads')
 
 
