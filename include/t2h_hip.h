@@ -227,7 +227,19 @@ typedef struct t2h_sample_heads_args {
   int32_t n_rows, n, C, n_class, n_heads;
   float* logits_ws;         /* optional scratch [n_rows][n_class]: the head GEMV of a row is then spread
                                over 8 workgroups and the race runs in a second launch (same results) */
+  /* philox_grid_threads != 0 (needs logits_ws): the Exp(1) noise of head h is NOT read from expo[h] but
+   * computed in the kernel as element (row * n_class + j) of the tensor torch's
+   * `torch.empty(n, n_class).exponential_()` would have drawn with generator seed philox_seed at
+   * generator offset philox_offset[h] (grid_threads = 256 * the grid ATen launches for that numel);
+   * the caller advances the generator by the draw's increment per ACTIVE head, in head order. */
+  uint64_t philox_seed;
+  uint64_t philox_offset[T2H_MAX_HEADS];
+  uint32_t philox_grid_threads;
 } t2h_sample_heads_args;
+/* element-by-element reproduction of `torch.empty(numel).exponential_()` on the device generator
+ * (seed, offset as the generator holds them BEFORE the draw; grid_threads as above) */
+int t2h_philox_exponential_f32(uint64_t seed, uint64_t offset, uint32_t grid_threads, float* out, int64_t numel,
+                               void* stream);
 int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream);
 
 /* Sampler training-time forward (models/transformer_model.py:212-274, forward only).

@@ -283,6 +283,49 @@ def test_sample_heads_one_launch_equals_per_head_launches():
     assert torch.equal(x_a, x_c) and torch.equal(out_a, out_c)
 
 
+@pytest.mark.parametrize('n', [4096, 512, 1536, 3 * 512 + 7])
+def test_philox_exponential_is_torchs_draw_bit_for_bit(n):
+    """t2h_philox_exponential_f32 == torch.empty(n, 1024).exponential_() on the device generator: every
+    element, several generator offsets, and the generator's own offset bookkeeping."""
+    K = 1024
+    torch.cuda.manual_seed_all(20210924 + n)
+    cur = torch.cuda.current_device()
+    gen = torch.cuda.default_generators[cur]
+    torch.rand(8, 512, device=DEV)                       # move the offset off zero like the sampler does
+    for _ in range(3):
+        seed, off = gen.initial_seed(), gen.get_offset()
+        ref = torch.empty(n, K, device=DEV).exponential_(1.0)
+        _, inc = ops.torch_draw_geometry(n * K)
+        assert gen.get_offset() == off + inc
+        got = ops.philox_exponential(seed, off, n * K, DEV).view(n, K)
+        assert torch.equal(got, ref), f'{int((got != ref).sum())} of {n * K} elements differ'
+
+
+def test_sample_heads_philox_mode_equals_explicit_draws():
+    n, C, K, H = 4096, 512, 1024, 18
+    hidden, g, b = rnd(n, C, seed=45) * 2, rnd(C, seed=46) * 0.1 + 1, rnd(C, seed=47) * 0.1
+    w = rnd(H, K, C, seed=48, scale=0.15)
+    gen_c = torch.Generator().manual_seed(50)
+    tex = torch.randint(0, H, (n, ), generator=gen_c)
+    rows = torch.randperm(n, generator=gen_c)[:40].to(torch.int32).to(DEV)
+    active = sorted(set(tex[rows.cpu().long()].tolist()))
+    dv = lambda t: t.to(DEV)
+    hidden, g, b, w, texd = dv(hidden), dv(g), dv(b), dv(w), dv(tex)
+    from text2human_amd import engine
+    noise = engine.TorchDeviceNoise(DEV)
+    torch.cuda.manual_seed_all(77)
+    expo = {h: noise.exponential(1, h, (n, K)) for h in active}
+    x_a, out_a = torch.full((n, ), 18432, dtype=torch.int64, device=DEV), torch.full((H, n), -1, dtype=torch.int64, device=DEV)
+    ops.sample_heads(hidden, g, b, w, expo, rows, rows.numel(), texd, 1.0, x_a, out_a)
+    end_state = torch.cuda.get_rng_state()
+    torch.cuda.manual_seed_all(77)
+    philox = noise.reserve_exponential(active, (n, K))
+    assert torch.equal(torch.cuda.get_rng_state(), end_state)   # the generator moved exactly as far
+    x_b, out_b = torch.full_like(x_a, 18432), torch.full_like(out_a, -1)
+    ops.sample_heads(hidden, g, b, w, {}, rows, rows.numel(), texd, 1.0, x_b, out_b, philox=philox)
+    assert torch.equal(x_a, x_b) and torch.equal(out_a, out_b)
+
+
 # ------------------------------------------------------------------ quantizer pieces
 
 

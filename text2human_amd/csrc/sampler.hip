@@ -278,6 +278,62 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
   if (tid == 0) out[b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- torch's `exponential_` draw, element by element.  The reference's Categorical.sample() draws
+// a FULL [n, n_class] Exp(1) tensor per active head from the device Philox generator
+// (models/sample_model.py:305-306 -> multinomial -> exponential_) although only the changed rows of
+// that head use it.  ATen's kernel (distribution_elementwise_grid_stride_kernel, unroll 4, block 256,
+// grid G) gives element e of the tensor the value
+//     u = uniform( philox4x32_10(key = seed, counter = {offset/4 + it, subsequence = idx})[ii] ),
+//     idx = e % (256 G), it = e / (256 G) / 4, ii = e / (256 G) % 4,
+//     q = u >= 1 - 2^-24 ? 2^-24 : -log(u)
+// (curand_init(seed, idx, offset) / curand_uniform4 = rocRAND's philox4x32_10 engine and
+// uniform_distribution; transformation::exponential of ATen/core/TransformationHelper.h).  Computing
+// it here for the (row, class) pairs that are actually used is bit-identical
+// (tests/test_gpu_kernels.py: full-tensor equality with torch) and removes a 16 MB draw per active
+// head and step.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t m0 = (uint64_t)0xD2511F53u * c[0], m1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0, hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
+  const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+  c[0] = n0;
+  c[1] = lo1;
+  c[2] = n2;
+  c[3] = lo0;
+}
+// log(x) exactly as it is compiled into ATen's kernel: LLVM's f32 log lowering for targets with fast FMA
+// (y = v_log_f32(x); r = y c; r + fma(y, cc, fma(y, c, -r)), c + cc = ln 2 to 49 bits).  Contraction
+// must stay off: fusing the last add into fma(c, y, t) counts the rounding error of r twice and is off
+// by one ulp for a third of the arguments (ocml's logf of ROCm 7.2 differs from ATen's build the same way).
+__device__ __forceinline__ float aten_logf(float x) {
+#pragma clang fp contract(off)
+  const float y = __builtin_amdgcn_logf(x), c = 0x1.62e42ep-1f, cc = 0x1.efa39ep-25f;
+  const float r = y * c;
+  const float t = __builtin_fmaf(y, cc, __builtin_fmaf(y, c, -r));
+  return r + t;
+}
+__device__ __forceinline__ float torch_exponential_at(uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t e) {
+  const uint64_t idx = e % grid_threads, m = e / grid_threads;
+  const uint64_t ctr = offset / 4 + (m >> 2);
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)idx, (uint32_t)(idx >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const uint32_t v = c[m & 3];
+  const float u = __builtin_fmaf((float)v, 2.3283064365386963e-10f, 2.3283064365386963e-10f);  // (0, 1]
+  const float lg = u >= 1.0f - 5.9604644775390625e-8f ? -5.9604644775390625e-8f : aten_logf(u);
+  return -lg;
+}
+
+__global__ void philox_exponential_kernel(uint64_t seed, uint64_t offset, uint32_t grid_threads, float* __restrict__ out,
+                                          int64_t numel) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < numel) out[e] = torch_exponential_at(seed, offset, grid_threads, (uint64_t)e);
+}
+
 // ---- two-launch form of the same tail (t2h_sample_heads with a logits workspace).  One workgroup
 // per changed row streams 2 MB of head weights by itself (~50 us per step with ~16 rows on 16 CUs);
 // here SL_SPLIT workgroups per row take n_class / SL_SPLIT classes each (LN_f recomputed per
@@ -361,11 +417,14 @@ __global__ __launch_bounds__(SH_THREADS) void sample_pick_kernel(const t2h_sampl
   mx = red[0];
 #pragma unroll
   for (int k = 1; k < NW; ++k) mx = fmaxf(mx, red[k]);
-  const float* er = a.expo[head] + (int64_t)row * a.n_class;
+  const float* er = a.philox_grid_threads ? nullptr : a.expo[head] + (int64_t)row * a.n_class;
   float best = -1.f;
   int best_j = 0x7fffffff;
   for (int j = tid; j < a.n_class; j += SH_THREADS) {
-    const float sc = expf(lg[j] - mx) / er[j];
+    const float q = er ? er[j]
+                       : torch_exponential_at(a.philox_seed, a.philox_offset[head], a.philox_grid_threads,
+                                              (uint64_t)row * a.n_class + j);
+    const float sc = expf(lg[j] - mx) / q;
     if (sc > best) {
       best = sc;
       best_j = j;
@@ -466,6 +525,8 @@ extern "C" int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream)
                   a.n_heads <= T2H_MAX_HEADS,
               "t2h_sample_heads: bad arguments");
   T2H_REQUIRE(a.C == 512, "t2h_sample_heads: C=%d unsupported (512)", a.C);
+  T2H_REQUIRE(a.philox_grid_threads == 0 || a.logits_ws != nullptr,
+              "t2h_sample_heads: the in-kernel exponential_ draw needs the two-launch form (logits_ws)");
   if (a.n_rows == 0) return T2H_OK;
   if (a.logits_ws) {  // two launches, SL_SPLIT workgroups per row stream the head weights
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -506,5 +567,14 @@ extern "C" int t2h_masked_ce_heads(const float* hidden, const float* lnf_gamma, 
                      w_heads, tex, mask, gt_lists, ce_rows, B * T, n_class, n_heads);
   hipLaunchKernelGGL(segment_sum_kernel, dim3(B), dim3(256), 0, s, ce_rows, ce_samples, T);
   T2H_CHECK_LAUNCH("t2h_masked_ce_heads");
+  return T2H_OK;
+}
+
+extern "C" int t2h_philox_exponential_f32(uint64_t seed, uint64_t offset, uint32_t grid_threads, float* out,
+                                          int64_t numel, void* stream) {
+  T2H_REQUIRE(out && numel > 0 && grid_threads > 0 && offset % 4 == 0, "t2h_philox_exponential_f32: bad arguments");
+  hipLaunchKernelGGL(philox_exponential_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), seed, offset, grid_threads, out, numel);
+  T2H_CHECK_LAUNCH("t2h_philox_exponential_f32");
   return T2H_OK;
 }

@@ -7,6 +7,8 @@ time, models/sample_model.py:220; every op is per-sample so batching is exact)
 and keeps activations as NHWC pixel rows [B*H*W, C] / token rows [B*T, C] in
 HBM.  PyTorch only allocates tensors and provides the stream.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -282,6 +284,23 @@ class TorchDeviceNoise:
     def exponential(self, step, head, shape):
         return torch.empty(shape, device=self.device).exponential_(1.0)
 
+    def reserve_exponential(self, heads, shape):
+        """The same consumption of the generator WITHOUT the draws: advances torch's device generator by
+        what one full `exponential_` of `shape` per head (ascending) would take and returns
+        (seed, {head: offset before its draw}); t2h_sample_heads then computes the few elements it
+        needs of those tensors itself (bit-identical, tests/test_gpu_kernels.py)."""
+        dev = torch.device(self.device)
+        index = dev.index if dev.index is not None else torch.cuda.current_device()  # (initialises CUDA)
+        gen = torch.cuda.default_generators[index]
+        _, inc = ops.torch_draw_geometry(shape[0] * shape[1], index)
+        off = gen.get_offset()
+        offsets = {}
+        for h in sorted(heads):
+            offsets[h] = off
+            off += inc
+        gen.set_offset(off)
+        return gen.initial_seed(), offsets
+
 
 class SplitOverflowError(_lib.T2HError):
     """An activation of the split-precision sampler left fp16's range."""
@@ -342,11 +361,17 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
         active = torch.nonzero(counts_host[:n_books]).flatten().tolist()
         if not active:
             continue
-        # the reference's draws, one full tensor per active head in ascending head order;
-        # then ONE launch samples every changed token with the head of its texture
-        expo = {cb: noise.exponential(t, cb, (n, n_class)).to(dev, torch.float32).contiguous() for cb in active}
+        # the reference's draws: one full [n, 1024] tensor per active head in ascending head order.
+        # On torch's device generator they are not materialised: the generator is advanced as if,
+        # and the sampling tail computes the elements of those tensors it needs (the changed rows).
+        # Other noise sources (tests replaying CPU draws) hand over explicit tensors.
+        if hasattr(noise, 'reserve_exponential') and os.environ.get('T2H_PHILOX_TAIL', '1') != '0':
+            expo, philox = {}, noise.reserve_exponential(active, (n, n_class))
+        else:
+            expo = {cb: noise.exponential(t, cb, (n, n_class)).to(dev, torch.float32).contiguous() for cb in active}
+            philox = None
         ops.sample_heads(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'], expo, rows,
-                         int(counts_host[n_books]), tex_flat, temp, x_t, out)
+                         int(counts_host[n_books]), tex_flat, temp, x_t, out, philox=philox)
         if step_hook is not None:
             step_hook(t, x_t, out)
     if net.split:

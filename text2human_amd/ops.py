@@ -444,10 +444,32 @@ def unmask_step(rand, t, unmasked, changes, tex, head_count, changed_rows=None, 
           't2h_unmask_step')
 
 
-def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex, temp, x_t, out_idx, split=True):
+def torch_draw_geometry(numel, device=None):
+    """(threads of the grid ATen launches for an elementwise random draw of `numel` floats, generator
+    offset increment of that draw) -- calc_execution_policy of ATen/native/cuda/DistributionTemplates.h:
+    block 256, grid = min(#CU * (max threads per CU / 256), ceil(numel / 256)), unroll 4."""
+    prop = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device())
+    grid = min(prop.multi_processor_count * (prop.max_threads_per_multi_processor // 256), (numel + 255) // 256)
+    return 256 * grid, ((numel - 1) // (256 * grid * 4) + 1) * 4
+
+
+def philox_exponential(seed, offset, numel, device):
+    """What `torch.empty(numel, device=device).exponential_()` returns on a generator with this seed /
+    offset, computed element by element (t2h_philox_exponential_f32)."""
+    out = torch.empty(numel, device=device, dtype=torch.float32)
+    gt, _ = torch_draw_geometry(numel, device)
+    check(_lib.load().t2h_philox_exponential_f32(int(seed), int(offset), gt, _p(out), numel, _stream()),
+          't2h_philox_exponential_f32')
+    return out
+
+
+def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex, temp, x_t, out_idx, split=True,
+                 philox=None):
     """All heads in one launch: `rows` (int32, first n_rows valid) are the changed token
     rows, expo_by_head {head: [n, n_class] Exp(1) draw}, w_heads [n_heads, n_class, C],
-    out_idx [n_heads, n]."""
+    out_idx [n_heads, n].  philox = (seed, {head: generator offset}): the noise of the listed heads is
+    computed in the kernel as the corresponding elements of torch's full-tensor exponential_ draws
+    instead of being read from expo_by_head."""
     _chk_f32(hidden, lnf_g, lnf_b, w_heads, *expo_by_head.values())
     n, C = hidden.shape
     n_heads, n_class = w_heads.shape[0], w_heads.shape[1]
@@ -460,9 +482,15 @@ def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex,
         a.expo[h] = e.data_ptr()
     a.rows, a.tex, a.x_t, a.out_idx = rows.data_ptr(), tex.data_ptr(), x_t.data_ptr(), out_idx.data_ptr()
     a.temp, a.n_rows, a.n, a.C, a.n_class, a.n_heads = float(temp), int(n_rows), n, C, n_class, n_heads
-    if split and n_rows > 0:  # logits scratch: 8 workgroups per row share the head weight stream
+    if (split or philox is not None) and n_rows > 0:  # logits scratch: 8 workgroups per row share the weight stream
         ws = torch.empty((int(n_rows), n_class), device=hidden.device, dtype=torch.float32)
         a.logits_ws = ws.data_ptr()
+    if philox is not None:
+        seed, offsets = philox
+        a.philox_seed = int(seed)
+        for h, off in offsets.items():
+            a.philox_offset[h] = int(off)
+        a.philox_grid_threads = torch_draw_geometry(n * n_class, hidden.device)[0]
     check(_lib.load().t2h_sample_heads(ctypes.byref(a), _stream()), 't2h_sample_heads')
 
 
