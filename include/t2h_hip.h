@@ -232,10 +232,14 @@ typedef struct t2h_sample_heads_args {
    * `torch.empty(n, n_class).exponential_()` would have drawn with generator seed philox_seed at
    * generator offset philox_offset[h] (grid_threads = 256 * the grid ATen launches for that numel);
    * the caller advances the generator by the draw's increment per ACTIVE head, in head order. */
+  int32_t hidden_compact;   /* != 0: `hidden` holds only the listed rows, hidden[i] = row rows[i] (the
+                               last layer's row-wise tail was evaluated for the changed rows only) */
   uint64_t philox_seed;
   uint64_t philox_offset[T2H_MAX_HEADS];
   uint32_t philox_grid_threads;
 } t2h_sample_heads_args;
+/* dst[i] = src[rows[i]], rows of row_bytes (multiple of 16) bytes */
+int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, int32_t n_rows, int32_t row_bytes, void* stream);
 /* element-by-element reproduction of `torch.empty(numel).exponential_()` on the device generator
  * (seed, offset as the generator holds them BEFORE the draw; grid_threads as above) */
 int t2h_philox_exponential_f32(uint64_t seed, uint64_t offset, uint32_t grid_threads, float* out, int64_t numel,

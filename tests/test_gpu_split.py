@@ -161,3 +161,27 @@ def test_sampler_net_split_mha_on_and_off_agree_with_oracle():
     ea, eb = (ln(a) - ref).abs().max().item(), (ln(b) - ref).abs().max().item()
     assert ea < 1e-4 and eb < 1e-4, (ea, eb)
     assert eb < 3 * ea + 1e-6, f'split attention path error {eb:.2e} vs fp32 attention {ea:.2e}'
+
+
+def test_last_layer_tail_on_the_changed_rows_only_matches_the_full_evaluation():
+    """engine.SamplerNet.hidden(defer_tail=True) + finish_tail(rows): the last layer's proj / LayerNorm /
+    fc1 / fc2 evaluated for a compact list of rows = those rows of the full forward (row-wise operators;
+    the small-M GEMM picks another tile configuration, so equality is to summation order)."""
+    sd = synthetic.fill(synthetic.transformer_schema(18432, 1024, 18, 512, 3, 512, 18), seed=12)
+    P = weights.Params(DEV)
+    desc = weights.pack_transformer(P, sd, 'tf')
+    gen = torch.Generator().manual_seed(21)
+    idx = torch.randint(0, 18433, (2, 512), generator=gen)
+    seg = torch.randint(0, 1024, (2, 512), generator=gen)
+    tex = torch.randint(0, 18, (2, 512), generator=gen)
+    args = (idx.to(DEV), seg.to(DEV), tex.to(DEV))
+    net = engine.SamplerNet(P, desc, 8, 'tf', split=True)
+    full = net.hidden(*args).clone()
+    rows = torch.randperm(1024, generator=gen)[:37].to(torch.int32).to(DEV)
+    net.hidden(*args, defer_tail=True)
+    got, compact = net.finish_tail(rows, 37)
+    assert compact and got.shape == (37, 512)
+    assert (got - full[rows.long()]).abs().max().item() < 2e-5
+    net.hidden(*args, defer_tail=True)                     # too many rows: the tail runs on all of them
+    got, compact = net.finish_tail(rows, 1000)
+    assert not compact and torch.equal(got, full)

@@ -53,7 +53,7 @@ class SampleHeadsArgs(ctypes.Structure):
         ('hidden', c_vp), ('lnf_gamma', c_vp), ('lnf_beta', c_vp), ('w_heads', c_vp),
         ('expo', c_vp * MAX_HEADS), ('rows', c_vp), ('tex', c_vp), ('x_t', c_vp), ('out_idx', c_vp),
         ('temp', c_f32), ('n_rows', c_i32), ('n', c_i32), ('C', c_i32), ('n_class', c_i32), ('n_heads', c_i32),
-        ('logits_ws', c_vp),
+        ('logits_ws', c_vp), ('hidden_compact', c_i32),
         ('philox_seed', ctypes.c_uint64), ('philox_offset', ctypes.c_uint64 * MAX_HEADS),
         ('philox_grid_threads', ctypes.c_uint32),
     ]
@@ -84,6 +84,7 @@ SIGNATURES = {
     't2h_mha_noncausal_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_unmask_step': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
     't2h_sample_heads': (ctypes.c_int, [ctypes.POINTER(SampleHeadsArgs), c_vp]),
+    't2h_gather_rows': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     't2h_philox_exponential_f32': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, c_vp, c_i64, c_vp]),
     't2h_q_sample': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp]),
     't2h_masked_ce_heads': (ctypes.c_int, [c_vp] * 9 + [c_i32] * 5 + [c_vp]),

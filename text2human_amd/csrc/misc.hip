@@ -330,3 +330,29 @@ extern "C" int t2h_tap_bias_map_f32(const float* tapc, float* out, int32_t B, in
   T2H_CHECK_LAUNCH("t2h_tap_bias_map_f32");
   return T2H_OK;
 }
+
+// dst[i] = src[rows[i]] for rows of row_bytes (multiple of 16) bytes: compacts the changed token rows
+// (residual stream, attention output as split rows) for the last layer's row-wise tail
+__global__ void gather_rows_kernel(const char* __restrict__ src, const int32_t* __restrict__ rows,
+                                   char* __restrict__ dst, int pieces_per_row, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t r = i / pieces_per_row;
+  const int pc = (int)(i - r * pieces_per_row);
+  *reinterpret_cast<f32x4*>(dst + (r * pieces_per_row + pc) * 16) =
+      *reinterpret_cast<const f32x4*>(src + ((int64_t)rows[r] * pieces_per_row + pc) * 16);
+}
+
+extern "C" int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, int32_t n_rows, int32_t row_bytes,
+                               void* stream) {
+  T2H_REQUIRE(src && rows && dst && n_rows >= 0 && row_bytes > 0 && row_bytes % 16 == 0 && t2h_aligned16(src) &&
+                  t2h_aligned16(dst),
+              "t2h_gather_rows: bad arguments (row_bytes %% 16, 16-byte alignment)");
+  if (n_rows == 0) return T2H_OK;
+  const int64_t total = (int64_t)n_rows * (row_bytes / 16);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const char*>(src), rows, static_cast<char*>(dst),
+                     row_bytes / 16, total);
+  T2H_CHECK_LAUNCH("t2h_gather_rows");
+  return T2H_OK;
+}

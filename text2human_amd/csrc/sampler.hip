@@ -349,7 +349,7 @@ __global__ __launch_bounds__(SL_THREADS) void sample_logits_kernel(const t2h_sam
   const int slot = blockIdx.x / SL_SPLIT, part = blockIdx.x - slot * SL_SPLIT;
   const int row = a.rows[slot];
   const int head = (int)a.tex[row];
-  const float* xr = a.hidden + (int64_t)row * C;
+  const float* xr = a.hidden + (int64_t)(a.hidden_compact ? slot : row) * C;
   f32x4 v[VPL];
   float s = 0.f;
 #pragma unroll
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(SH_THREADS) void sample_heads_kernel(const t2h_samp
   const float* expo = a.expo[head];
   if (expo == nullptr) return;  // cannot happen: a head with changed tokens always drew its noise
   sample_row<C>(lds, row, a.hidden, a.lnf_gamma, a.lnf_beta, a.w_heads + (int64_t)head * a.n_class * C, expo, head,
-                1.0f / a.temp, a.x_t, a.out_idx + (int64_t)head * a.n, a.n_class);
+                1.0f / a.temp, a.x_t, a.out_idx + (int64_t)head * a.n, a.n_class);  // (full hidden only)
 }
 
 }  // namespace
@@ -525,6 +525,7 @@ extern "C" int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream)
                   a.n_heads <= T2H_MAX_HEADS,
               "t2h_sample_heads: bad arguments");
   T2H_REQUIRE(a.C == 512, "t2h_sample_heads: C=%d unsupported (512)", a.C);
+  T2H_REQUIRE(!a.hidden_compact || a.logits_ws != nullptr, "t2h_sample_heads: compact hidden needs the two-launch form");
   T2H_REQUIRE(a.philox_grid_threads == 0 || a.logits_ws != nullptr,
               "t2h_sample_heads: the in-kernel exponential_ draw needs the two-launch form (logits_ws)");
   if (a.n_rows == 0) return T2H_OK;

@@ -165,6 +165,7 @@ class SamplerNet:
         # latency / first-tile fill / epilogue tail overlaps the other's main loops
         self.n_streams = n_streams
         self._streams = None
+        self._deferred = None
         # split_mha (with split): attention on the fp16 matrix cores too -- the q|k|v
         # projection writes q, k as split rows and v as transposed planes, no fp32 qkv
         self.split_mha = split_mha
@@ -181,7 +182,14 @@ class SamplerNet:
                                    vt=ops.vt_empty(M // 512 if M % 512 == 0 else 1, self.n_head, 512, dev))}
         return self._buf[key]
 
-    def hidden(self, idx, segm_tok, tex_tok):
+    # The LAST layer's row-wise tail (proj + residual, LayerNorm, fc1 + GELU, fc2 + residual) only
+    # matters for the rows whose logits are sampled this step -- ~16 of 4096 at B=8.  With
+    # defer_tail=True, hidden() stops after the last layer's attention; finish_tail() evaluates the
+    # tail on the compacted changed rows once the host knows how many there are (the Linears, the
+    # LayerNorm and the residual adds are row-wise, so those rows come out as in the full evaluation).
+    TRIM_MAX_ROWS = 256
+
+    def hidden(self, idx, segm_tok, tex_tok, defer_tail=False):
         P, nm = self.P, self.name
         B, T = idx.shape
         C = self.desc['C']
@@ -205,7 +213,7 @@ class SamplerNet:
             Bs = B // ns
             sl = [(j * Bs * T, (j + 1) * Bs * T, j * Bs, (j + 1) * Bs) for j in range(ns)]
 
-            def layer(i, lo, hi, b0, b1):
+            def layer(i, lo, hi, b0, b1, tail=True):
                 p = f'{nm}.{i}'
                 m, xs = hi - lo, x[lo:hi]
                 ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])
@@ -218,6 +226,8 @@ class SamplerNet:
                     ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out=qkv[lo:hi],
                                    bias=P[f'{p}.qkv.b'])
                     ops.mha_noncausal_split(qkv[lo:hi], b1 - b0, T, self.n_head, ys[lo:hi])
+                if not tail:
+                    return
                 ops.gemm_split(ys[lo:hi], P[f'{p}.proj.w_split'], m, C, C, out=xs, bias=P[f'{p}.proj.b'],
                                residual=xs)
                 ops.layernorm_split(xs, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs[lo:hi])
@@ -226,9 +236,14 @@ class SamplerNet:
                 ops.gemm_split(us[lo:hi], P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xs, bias=P[f'{p}.fc2.b'],
                                residual=xs)
 
+            self._deferred = None
             if ns == 1:
-                for i in range(self.desc['n_layers']):
+                L = self.desc['n_layers']
+                for i in range(L - 1):
                     layer(i, *sl[0])
+                layer(L - 1, *sl[0], tail=not defer_tail)
+                if defer_tail:
+                    self._deferred = (x, ys, M, C)
                 return x
             if self._streams is None or len(self._streams) != ns:
                 self._streams = [torch.cuda.Stream(device=idx.device) for _ in range(ns)]
@@ -252,6 +267,28 @@ class SamplerNet:
             ops.gemm(h, P[f'{p}.fc1.w'], out=u, bias=P[f'{p}.fc1.b'], act=ACT_GELU)
             ops.gemm(u, P[f'{p}.fc2.w'], out=x, bias=P[f'{p}.fc2.b'], residual=x)
         return x
+
+    def finish_tail(self, rows, n_rows):
+        """After hidden(..., defer_tail=True): the last layer's row-wise tail.  Returns (hidden, compact):
+        compact=True -> hidden[i] is row rows[i] (only the first n_rows rows of the list were evaluated)."""
+        x, ys, M, C = self._deferred
+        self._deferred = None
+        P = self.P
+        p = f"{self.name}.{self.desc['n_layers'] - 1}"
+        if 0 < n_rows <= self.TRIM_MAX_ROWS:
+            m = int(n_rows)
+            xc, yc = ops.gather_rows(x, rows, m), ops.gather_rows(ys, rows, m)
+            hc, uc = ops.split_rows_empty(m, C, x.device), ops.split_rows_empty(m, 4 * C, x.device)
+            compact = True
+        else:
+            m, xc, yc, compact = M, x, ys, False
+            buf = self._buffers(M, C, x.device)
+            hc, uc = buf['h_split'], buf['u_split']
+        ops.gemm_split(yc, P[f'{p}.proj.w_split'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc)
+        ops.layernorm_split(xc, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hc)
+        ops.gemm_split(hc, P[f'{p}.fc1.w_split'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.b'], act=ACT_GELU)
+        ops.gemm_split(uc, P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xc, bias=P[f'{p}.fc2.b'], residual=xc)
+        return xc, compact
 
     def logits(self, idx, segm_tok, tex_tok, heads=None):
         """Full [B*T, 1024] logits per head (tests / API parity only; the
@@ -356,11 +393,16 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
         ops.unmask_step(rnd, t, unmasked, changes, tex_flat, counts, rows, n_books)
         counts_host.copy_(counts, non_blocking=True)
         ev.record()
-        hidden = net.hidden(x_t, segm_tok, tex_tok)
+        defer = bool(getattr(net, 'split', False) and getattr(net, 'split_mha', False) and net.n_streams == 1
+                     and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
+        hidden = net.hidden(x_t, segm_tok, tex_tok, defer_tail=defer)
         ev.synchronize()
         active = torch.nonzero(counts_host[:n_books]).flatten().tolist()
         if not active:
             continue
+        compact = False
+        if defer and net._deferred is not None:
+            hidden, compact = net.finish_tail(rows, int(counts_host[n_books]))
         # the reference's draws: one full [n, 1024] tensor per active head in ascending head order.
         # On torch's device generator they are not materialised: the generator is advanced as if,
         # and the sampling tail computes the elements of those tensors it needs (the changed rows).
@@ -371,7 +413,7 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
             expo = {cb: noise.exponential(t, cb, (n, n_class)).to(dev, torch.float32).contiguous() for cb in active}
             philox = None
         ops.sample_heads(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'], expo, rows,
-                         int(counts_host[n_books]), tex_flat, temp, x_t, out, philox=philox)
+                         int(counts_host[n_books]), tex_flat, temp, x_t, out, philox=philox, hidden_compact=compact)
         if step_hook is not None:
             step_hook(t, x_t, out)
     if net.split:

@@ -463,15 +463,28 @@ def philox_exponential(seed, offset, numel, device):
     return out
 
 
+def gather_rows(src, rows, n_rows, out=None):
+    """out[i] = src[rows[i]] (rows int32 on the device, first n_rows used); src 2-D+ contiguous, any dtype
+    whose row is a multiple of 16 bytes."""
+    assert src.is_contiguous() and rows.dtype == torch.int32
+    row_bytes = src[0].numel() * src.element_size()
+    if out is None:
+        out = torch.empty((int(n_rows), ) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    check(_lib.load().t2h_gather_rows(_p(src), _p(rows), _p(out), int(n_rows), row_bytes, _stream()), 't2h_gather_rows')
+    return out
+
+
 def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex, temp, x_t, out_idx, split=True,
-                 philox=None):
+                 philox=None, hidden_compact=False):
     """All heads in one launch: `rows` (int32, first n_rows valid) are the changed token
     rows, expo_by_head {head: [n, n_class] Exp(1) draw}, w_heads [n_heads, n_class, C],
     out_idx [n_heads, n].  philox = (seed, {head: generator offset}): the noise of the listed heads is
     computed in the kernel as the corresponding elements of torch's full-tensor exponential_ draws
     instead of being read from expo_by_head."""
     _chk_f32(hidden, lnf_g, lnf_b, w_heads, *expo_by_head.values())
-    n, C = hidden.shape
+    C = hidden.shape[1]
+    n = out_idx.shape[1]
+    assert hidden.shape[0] == (int(n_rows) if hidden_compact else n)
     n_heads, n_class = w_heads.shape[0], w_heads.shape[1]
     assert w_heads.is_contiguous() and out_idx.is_contiguous() and out_idx.shape == (n_heads, n)
     a = _lib.SampleHeadsArgs()
@@ -482,7 +495,8 @@ def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex,
         a.expo[h] = e.data_ptr()
     a.rows, a.tex, a.x_t, a.out_idx = rows.data_ptr(), tex.data_ptr(), x_t.data_ptr(), out_idx.data_ptr()
     a.temp, a.n_rows, a.n, a.C, a.n_class, a.n_heads = float(temp), int(n_rows), n, C, n_class, n_heads
-    if (split or philox is not None) and n_rows > 0:  # logits scratch: 8 workgroups per row share the weight stream
+    a.hidden_compact = int(bool(hidden_compact))
+    if (split or philox is not None or hidden_compact) and n_rows > 0:  # logits scratch: 8 workgroups per row share the weight stream
         ws = torch.empty((int(n_rows), n_class), device=hidden.device, dtype=torch.float32)
         a.logits_ws = ws.data_ptr()
     if philox is not None:
