@@ -78,6 +78,11 @@ typedef struct t2h_gemm_args {
   int32_t ups;            /* 1: input is nearest-upsampled x2 on the fly */
   int32_t batch;          /* >=1: independent problems (blockIdx.z) */
   int64_t strideA, strideB, strideC; /* element strides between problems */
+  /* t2h_conv_split_f32 only: if set, the epilogue also writes per-channel (sum, sum of squares) of the
+   * FINAL output values over every 128-row tile, in fp64: gn_part_out[img][chunk][2][N], chunk = tile
+   * index inside the image (rows per image / 128 chunks) -- the partial layout
+   * t2h_groupnorm_finalize_f32 reduces, so the GroupNorm that follows needs no pass over the tensor */
+  double* gn_part_out;
 } t2h_gemm_args;
 
 int t2h_gemm_f32(const t2h_gemm_args* args, void* stream);
@@ -170,6 +175,11 @@ int t2h_groupnorm_tables_f32(const float* x, int32_t ldx, const float* gamma,
                              const float* beta, float* scale, float* shift,
                              int32_t n_img, int32_t HW, int32_t C, int32_t groups,
                              float eps, void* workspace, void* stream);
+/* the second half of it: tables from per-chunk partial sums part[n_img][chunks][2][C] (fp64), as
+ * t2h_conv_split_f32's epilogue writes them (t2h_gemm_args.gn_part_out) */
+int t2h_groupnorm_finalize_f32(const double* part, int32_t chunks, const float* gamma, const float* beta,
+                               float* scale, float* shift, int32_t n_img, int32_t HW, int32_t C,
+                               int32_t groups, float eps, void* stream);
 
 /* in-place row softmax of [rows, n] (AttnBlock, vqgan_arch.py:647) */
 int t2h_softmax_rows_f32(float* x, int32_t rows, int32_t n, int32_t ld, void* stream);

@@ -49,7 +49,7 @@ def test_gemm_args_layout_matches_header():
     body = src[src.index('typedef struct t2h_gemm_args {'):src.index('} t2h_gemm_args;')]
     body = re.sub(r'/\*.*?\*/', '', body[body.index('{') + 1:], flags=re.S)
     fields = []
-    for m in re.finditer(r'(?:const\s+float\*|float\*|int32_t|int64_t|float)\s+([^;]+);', body):
+    for m in re.finditer(r'(?:const\s+float\*|float\*|double\*|int32_t|int64_t|float)\s+([^;]+);', body):
         fields += [n.strip() for n in m.group(1).split(',')]
     assert fields == [f[0] for f in _lib.GemmArgs._fields_]
 

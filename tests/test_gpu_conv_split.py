@@ -52,9 +52,18 @@ def test_conv3x3_split(mode, cin, cout, h, w):
         ho, wo = ref.shape[2:]
         assert ops.conv_split_ok(ho * wo, mode)
         res = rnd(n_img * ho * wo, cout, seed=18)
-        out = ops.conv_split(xs, ws, n_img, h, w, cin, cout, bias=b.to(DEV), residual=res.to(DEV), mode=mode)
+        out = ops.conv_split(xs, ws, n_img, h, w, cin, cout, bias=b.to(DEV), residual=res.to(DEV), mode=mode,
+                             gn_stats=True)
         ref_rows = ref.permute(0, 2, 3, 1).reshape(-1, cout) + res.double()
         assert_close(out, ref_rows, what=f'{mode} pro={use_pro}')
+        # GroupNorm tables from the epilogue's partial sums == tables from a pass over the tensor
+        gam, bet = rnd(cout, seed=30).to(DEV), rnd(cout, seed=31).to(DEV)
+        if cout % 128 == 0:                                      # (channel counts the plain pass serves)
+            sc_e, sh_e = ops.groupnorm_tables(out, gam, bet, n_img, ho * wo)
+            plain = out.clone()                                  # (a clone carries no partials)
+            assert not hasattr(plain, '_t2h_gn_part') and hasattr(out, '_t2h_gn_part')
+            sc_p, sh_p = ops.groupnorm_tables(plain, gam, bet, n_img, ho * wo)
+            assert (sc_e - sc_p).abs().max().item() < 1e-6 and (sh_e - sh_p).abs().max().item() < 1e-6
         # and no worse than twice the exact-fp32 kernel's own distance from fp64
         o32 = ops.conv3x3(rows, wp, n_img, h, w, cin, bias=b.to(DEV), residual=res.to(DEV), mode=mode,
                           pro=(sc.to(DEV), sh.to(DEV), ops.PRO_SWISH) if use_pro else None)

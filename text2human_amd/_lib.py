@@ -32,6 +32,7 @@ class GemmArgs(ctypes.Structure):
         ('Hin', c_i32), ('Win', c_i32), ('Cin', c_i32), ('Hout', c_i32), ('Wout', c_i32),
         ('stride', c_i32), ('pad', c_i32), ('ups', c_i32), ('batch', c_i32),
         ('strideA', c_i64), ('strideB', c_i64), ('strideC', c_i64),
+        ('gn_part_out', c_vp),
     ]
 
 
@@ -79,6 +80,7 @@ SIGNATURES = {
     't2h_groupnorm_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32]),
     't2h_groupnorm_tables_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                                 c_i32, c_i32, c_f32, c_vp, c_vp]),
+    't2h_groupnorm_finalize_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     't2h_softmax_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_embed_sum4_f32': (ctypes.c_int, [c_vp] * 8 + [c_i32, c_i32, c_i32, c_vp]),
     't2h_mha_noncausal_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -266,6 +266,46 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
     }
     *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = va;
     *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col + 4) = vb;
+    if (p.gn_part_out) {  // final values back into the staging tile for the column sums below
+      *reinterpret_cast<f32x4*>(Ot + rl * O_LD + c8) = va;
+      *reinterpret_cast<f32x4*>(Ot + rl * O_LD + c8 + 4) = vb;
+    }
+  }
+  // ---- GroupNorm partials of the tensor this kernel produces: per output channel, (sum, sum of
+  // squares) of the FINAL values over the tile's 128 rows, in fp64, fixed order: lane j sums column j of
+  // its wave tile over the 32 rows, the four M-waves are added through LDS, one plain store per
+  // (tile, channel) -- no atomics, bit-reproducible.  The following GroupNorm only reduces
+  // rows/128 partials per channel instead of reading the tensor again (the gn_partial pass was 15 %
+  // of the decode).
+  if (p.gn_part_out) {
+    __syncthreads();
+    double su = 0.0, sq = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < WM; ++r) {
+      const double v = (double)Ot[r * O_LD + lane];
+      su += v;
+      sq = fma(v, v, sq);
+    }
+    __syncthreads();  // every wave is done reading its staging tile: reuse the start of LDS as the table
+    double* const red = reinterpret_cast<double*>(smem);  // [wave][64][2]
+    red[(wave * 64 + lane) * 2] = su;
+    red[(wave * 64 + lane) * 2 + 1] = sq;
+    __syncthreads();
+    if (wave < CS_WN) {  // the two N-waves of M-wave 0 combine the four M-waves of their columns
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int wmi = 0; wmi < CS_WM; ++wmi) {
+        a += red[((wmi * CS_WN + wave) * 64 + lane) * 2];
+        b += red[((wmi * CS_WN + wave) * 64 + lane) * 2 + 1];
+      }
+      const int col = n0 + wave * WN + lane;
+      if (col < p.N) {
+        const int chunks = hw / CS_BM, chunk = (m0 - img * hw) / CS_BM;
+        double* dst = p.gn_part_out + (((int64_t)img * chunks + chunk) * 2) * p.N + col;
+        dst[0] = a;
+        dst[p.N] = b;
+      }
+    }
   }
 }
 

@@ -162,7 +162,22 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int chunks, 
   __shared__ float g_mean[64], g_rstd[64];
   const int c = threadIdx.x, img = blockIdx.x;
   double s = 0, ss = 0;
-  for (int k = 0; k < chunks; ++k) {
+  int k = 0;
+  for (; k + 8 <= chunks; k += 8) {  // 16 independent loads in flight (up to 1024 chunks when the partials
+    double a[8], b[8];               // come from a conv epilogue); the additions stay in chunk order
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double* p = part + (((int64_t)img * chunks + k + j) * 2) * C;
+      a[j] = p[c];
+      b[j] = p[C + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s += a[j];
+      ss += b[j];
+    }
+  }
+  for (; k < chunks; ++k) {
     const double* p = part + (((int64_t)img * chunks + k) * 2) * C;
     s += p[c];
     ss += p[C + c];
@@ -291,6 +306,18 @@ extern "C" int t2h_groupnorm_tables_f32(const float* x, int32_t ldx, const float
                      static_cast<const double*>(workspace), chunks, HW, C, groups, eps, gamma, beta,
                      scale, shift);
   T2H_CHECK_LAUNCH("t2h_groupnorm_tables_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_groupnorm_finalize_f32(const double* part, int32_t chunks, const float* gamma, const float* beta,
+                                          float* scale, float* shift, int32_t n_img, int32_t HW, int32_t C,
+                                          int32_t groups, float eps, void* stream) {
+  T2H_REQUIRE(part && gamma && beta && scale && shift, "t2h_groupnorm_finalize_f32: NULL pointer");
+  T2H_REQUIRE(n_img > 0 && HW > 0 && chunks > 0 && C > 0 && C <= 1024 && groups > 0 && groups <= 64 && C % groups == 0,
+              "t2h_groupnorm_finalize_f32: bad shape (C <= 1024, groups <= 64)");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img), dim3(C), 0, static_cast<hipStream_t>(stream), part, chunks, HW,
+                     C, groups, eps, gamma, beta, scale, shift);
+  T2H_CHECK_LAUNCH("t2h_groupnorm_finalize_f32");
   return T2H_OK;
 }
 

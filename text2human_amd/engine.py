@@ -48,7 +48,8 @@ class VQGANStack:
         if ws is not None:
             xs = ops.gn_apply_split(x, *(pro or (None, None)), rows_per_img=h * w,
                                     act=PRO_SWISH if pro is not None else PRO_NONE)
-            return ops.conv_split(xs, ws, n_img, h, w, cin, cout, bias=P[f'{conv}.b'], residual=residual, mode=mode)
+            return ops.conv_split(xs, ws, n_img, h, w, cin, cout, bias=P[f'{conv}.b'], residual=residual, mode=mode,
+                                  gn_stats=cout <= 1024)
         return ops.conv3x3(x, P[f'{conv}.w'], n_img, h, w, cin, bias=P[f'{conv}.b'], mode=mode, residual=residual,
                            pro=(pro[0], pro[1], PRO_SWISH) if pro is not None else None)
 
@@ -60,7 +61,7 @@ class VQGANStack:
             xs = ops.gn_apply_split(x, *(pro or (None, None)), rows_per_img=n_rows_img)
             cout, cin = P[f'{key}.w'].shape
             return ops.conv_split(xs, ws, x.shape[0] // n_rows_img, n_rows_img, 1, cin, cout, taps=1,
-                                  bias=P[f'{key}.b'], residual=residual)
+                                  bias=P[f'{key}.b'], residual=residual, gn_stats=cout <= 1024)
         return ops.gemm(x, P[f'{key}.w'], bias=P[f'{key}.b'], residual=residual,
                         pro=(pro[0], pro[1], n_rows_img, PRO_NONE) if pro is not None else None)
 

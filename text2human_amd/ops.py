@@ -162,7 +162,7 @@ def gn_apply_split(x, scale=None, shift=None, rows_per_img=0, act=PRO_NONE, out=
 
 
 def conv_split(xs, w_split, n_img, hin, win, cin, cout, taps=9, out=None, bias=None, residual=None,
-               act=ACT_NONE, mode='same', res_pre=False):
+               act=ACT_NONE, mode='same', res_pre=False, gn_stats=False):
     """Stride-1 convolution (taps 9: 3x3 'same' or, mode 'up', 3x3 after nearest x2; taps 1: 1x1) of
     split-row activations xs [n_img*hin*win, cin/32, 2, 32] with split-row weights
     w_split [cout, taps*cin/32, 2, 32] on the fp16 matrix cores; fp32 rows out [M, cout]."""
@@ -185,7 +185,13 @@ def conv_split(xs, w_split, n_img, hin, win, cin, cout, taps=9, out=None, bias=N
     g.a_mode, g.epi_act, g.alpha, g.res_pre = 1, act, 1.0, int(res_pre)
     g.Hin, g.Win, g.Cin, g.Hout, g.Wout = hin, win, cin, hout, wout
     g.stride, g.pad, g.ups, g.batch = 1, (1 if taps == 9 else 0), ups, 1
+    part = None
+    if gn_stats:  # per-(image, 128-row tile, channel) fp64 (sum, sum of squares) of the output, from the epilogue
+        part = torch.empty((n_img, hout * wout // 128, 2, cout), device=xs.device, dtype=torch.float64)
+        g.gn_part_out = part.data_ptr()
     _launch_conv_split(g, 2.0 * M * cout * taps * cin)
+    if part is not None:
+        out._t2h_gn_part = part  # groupnorm_tables(out, ...) then only reduces these partials
     return out
 
 
@@ -390,10 +396,16 @@ def groupnorm_tables(x, gamma, beta, n_img, hw, groups=32, eps=1e-6):
     _chk_f32(x, gamma, beta)
     C = gamma.shape[0]
     lib = _lib.load()
-    ws = torch.empty(lib.t2h_groupnorm_workspace_bytes(n_img, hw, C) // 8, device=x.device,
-                     dtype=torch.float64)
     scale = torch.empty((n_img, C), device=x.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
+    part = getattr(x, '_t2h_gn_part', None)
+    if part is not None and tuple(part.shape[:1] + part.shape[2:]) == (n_img, 2, C) and x.shape[0] == n_img * hw:
+        # the producing conv already left per-tile partial sums: no pass over x
+        check(lib.t2h_groupnorm_finalize_f32(_p(part), part.shape[1], _p(gamma), _p(beta), _p(scale), _p(shift),
+                                             n_img, hw, C, groups, eps, _stream()), 't2h_groupnorm_finalize_f32')
+        return scale, shift
+    ws = torch.empty(lib.t2h_groupnorm_workspace_bytes(n_img, hw, C) // 8, device=x.device,
+                     dtype=torch.float64)
     check(lib.t2h_groupnorm_tables_f32(_p(x), _rows(x), _p(gamma), _p(beta), _p(scale), _p(shift),
                                        n_img, hw, C, groups, eps, _p(ws), _stream()),
           't2h_groupnorm_tables_f32')
