@@ -103,6 +103,7 @@ int t2h_gemm_force_config(int cfg);
  * C, residual, bias stay fp32.  Replaces t2h_gemm_f32 at vqgan_arch.py:597-617,529-534,636-661,
  * 1000-1033,1136-1151 (opt-out: T2H_SPLIT_CONV=0). */
 int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
+int t2h_conv_split_force_tile(int rows); /* tuning / tests: 128 or 256 output pixels per tile, 0 auto; returns the old value */
 /* out_split[row] = split( act( x[row] * scale[img] + shift[img] ) ): GroupNorm apply (tables of
  * t2h_groupnorm_tables_f32; NULL = plain split) + swish (act 1) of fp32 NHWC rows in one pass
  * (vqgan_arch.py:510-517,599-600,609-610,637,1026-1027) */

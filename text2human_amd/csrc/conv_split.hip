@@ -33,12 +33,10 @@ namespace {
 typedef t2h_f16x8 f16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CS_BM = 128, CS_BN = 128, CS_WM = 4, CS_WN = 2, CS_NT = 64 * CS_WM * CS_WN;
+// tile: CS_BM (128 or 256) x 128, 8 waves as 4 (M) x 2 (N): 32x64 or 64x64 wave tiles
+constexpr int CS_BN = 128, CS_WM = 4, CS_WN = 2, CS_NT = 64 * CS_WM * CS_WN;
 constexpr int CS_LDS_ROW = 144;                     // bytes per tile row in LDS
-constexpr int CS_LA = CS_BM * 8 / CS_NT;            // A pieces per thread and K tile (2)
 constexpr int CS_LB = CS_BN * 8 / CS_NT;            // B pieces per thread and K tile (2)
-constexpr int CS_L = CS_LA + CS_LB;
-static_assert(CS_BM * 8 % CS_NT == 0 && CS_BN * 8 % CS_NT == 0, "pieces per thread");
 
 __device__ __forceinline__ void cs_gload16(u32x4& dst, const void* ptr) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
@@ -48,8 +46,12 @@ __device__ __forceinline__ void cs_wait(u32x4& v) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
+template <int CS_BM>
 __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_args p) {
-  constexpr int WM = CS_BM / CS_WM, WN = CS_BN / CS_WN;  // 32 x 64 wave tile
+  constexpr int CS_LA = CS_BM * 8 / CS_NT;  // A pieces per thread and K tile (2 or 4)
+  constexpr int CS_L = CS_LA + CS_LB;
+  static_assert(CS_BM * 8 % CS_NT == 0 && CS_BN * 8 % CS_NT == 0 && CS_BM % 128 == 0, "tile / thread shape");
+  constexpr int WM = CS_BM / CS_WM, WN = CS_BN / CS_WN;  // 32x64 or 64x64 wave tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int BUF_B = (CS_BM + CS_BN) * CS_LDS_ROW;
   constexpr int O_LD = WN + 4;
@@ -207,12 +209,10 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
     __syncthreads();
   };
   static_assert(NMMA - 2 * CS_L + 1 >= 1, "not enough matrix instructions to pin the staged pieces behind");
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
+  for (int kt = 0; kt < nk; kt += 2) {  // no peeled odd tail: a third copy of step() costs registers
     step(kt, set1{});
-    step(kt + 1, set0{});
+    if (kt + 1 < nk) step(kt + 1, set0{});
   }
-  if (nk & 1) step(nk - 1, set1{});
 #pragma unroll
   for (int S = 0; S < 2; ++S)
 #pragma unroll
@@ -272,9 +272,9 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
     }
   }
   // ---- GroupNorm partials of the tensor this kernel produces: per output channel, (sum, sum of
-  // squares) of the FINAL values over the tile's 128 rows, in fp64, fixed order: lane j sums column j of
-  // its wave tile over the 32 rows, the four M-waves are added through LDS, one plain store per
-  // (tile, channel) -- no atomics, bit-reproducible.  The following GroupNorm only reduces
+  // squares) of the FINAL values over every 128 rows, in fp64, fixed order: lane j sums column j of its
+  // wave tile over its rows, the M-waves of a 128-row chunk are added through LDS, one plain store per
+  // (chunk, channel) -- no atomics, bit-reproducible.  The following GroupNorm only reduces
   // rows/128 partials per channel instead of reading the tensor again (the gn_partial pass was 15 %
   // of the decode).
   if (p.gn_part_out) {
@@ -291,16 +291,20 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
     red[(wave * 64 + lane) * 2] = su;
     red[(wave * 64 + lane) * 2 + 1] = sq;
     __syncthreads();
-    if (wave < CS_WN) {  // the two N-waves of M-wave 0 combine the four M-waves of their columns
+    // partials are per 128 rows whatever the tile: 128 / WM consecutive M-waves per chunk; the first
+    // M-wave of each chunk adds its group in fixed order and stores
+    constexpr int WPC = 128 / WM;  // M-waves per 128-row chunk
+    const int wmi0 = wave / CS_WN, wni = wave % CS_WN;
+    if (wmi0 % WPC == 0) {
       double a = 0.0, b = 0.0;
 #pragma unroll
-      for (int wmi = 0; wmi < CS_WM; ++wmi) {
-        a += red[((wmi * CS_WN + wave) * 64 + lane) * 2];
-        b += red[((wmi * CS_WN + wave) * 64 + lane) * 2 + 1];
+      for (int k = 0; k < WPC; ++k) {
+        a += red[(((wmi0 + k) * CS_WN + wni) * 64 + lane) * 2];
+        b += red[(((wmi0 + k) * CS_WN + wni) * 64 + lane) * 2 + 1];
       }
-      const int col = n0 + wave * WN + lane;
+      const int col = n0 + wni * WN + lane;
       if (col < p.N) {
-        const int chunks = hw / CS_BM, chunk = (m0 - img * hw) / CS_BM;
+        const int chunks = hw / 128, chunk = (m0 - img * hw) / 128 + wmi0 / WPC;
         double* dst = p.gn_part_out + (((int64_t)img * chunks + chunk) * 2) * p.N + col;
         dst[0] = a;
         dst[p.N] = b;
@@ -309,7 +313,15 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
   }
 }
 
+int g_force_bm = 0;
+
 }  // namespace
+
+extern "C" int t2h_conv_split_force_tile(int rows) {
+  const int old = g_force_bm;
+  g_force_bm = (rows == 128 || rows == 256) ? rows : 0;
+  return old;
+}
 
 extern "C" int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream) {
   T2H_REQUIRE(args != nullptr, "t2h_conv_split_f32: args is NULL");
@@ -323,7 +335,7 @@ extern "C" int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream) {
               "t2h_conv_split_f32: stride-1 'same' / nearest-x2 / 1x1 convolutions only");
   T2H_REQUIRE(a.Hout == (a.Hin << a.ups) && a.Wout == (a.Win << a.ups) && a.M % (a.Hout * a.Wout) == 0,
               "t2h_conv_split_f32: geometry");
-  T2H_REQUIRE((a.Hout * a.Wout) % CS_BM == 0, "t2h_conv_split_f32: pixels per image must be a multiple of %d", CS_BM);
+  T2H_REQUIRE((a.Hout * a.Wout) % 128 == 0, "t2h_conv_split_f32: pixels per image must be a multiple of 128");
   T2H_REQUIRE(a.N % 8 == 0 && a.ldc % 4 == 0 && (!a.residual || a.ldr % 4 == 0) &&
                   t2h_aligned16(a.A) && t2h_aligned16(a.B) && t2h_aligned16(a.C) &&
                   (!a.residual || t2h_aligned16(a.residual)),
@@ -331,8 +343,16 @@ extern "C" int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream) {
   T2H_REQUIRE(a.epi_act == 0 || a.epi_act == 2, "t2h_conv_split_f32: epilogue activation none / ReLU");
   T2H_REQUIRE(a.pro_scale == nullptr && a.pro_shift == nullptr,
               "t2h_conv_split_f32: no prologue tables (apply GroupNorm with t2h_gn_apply_split_f32)");
-  dim3 grid(((a.N + CS_BN - 1) / CS_BN) * ((a.M + CS_BM - 1) / CS_BM)), block(CS_NT);
-  hipLaunchKernelGGL(conv_split_kernel, grid, block, 0, static_cast<hipStream_t>(stream), a);
+  // 256-row tiles (64x64 wave tiles: 8 fragment reads per 12 matrix instructions instead of 6 per 6)
+  // where they still give every CU a tile; t2h_conv_split_force_tile() overrides (tests, A/B)
+  const int nbx = (a.N + CS_BN - 1) / CS_BN;
+  const bool big = g_force_bm ? g_force_bm == 256
+                              : ((a.Hout * a.Wout) % 256 == 0 && (int64_t)(a.M / 256) * nbx >= 256);
+  T2H_REQUIRE(!big || (a.Hout * a.Wout) % 256 == 0, "t2h_conv_split_f32: 256-row tiles need pixels per image %% 256 == 0");
+  dim3 block(CS_NT);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (big) hipLaunchKernelGGL(conv_split_kernel<256>, dim3(nbx * ((a.M + 255) / 256)), block, 0, s, a);
+  else hipLaunchKernelGGL(conv_split_kernel<128>, dim3(nbx * ((a.M + 127) / 128)), block, 0, s, a);
   T2H_CHECK_LAUNCH("t2h_conv_split_f32");
   return T2H_OK;
 }

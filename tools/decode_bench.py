@@ -20,8 +20,10 @@ batch = synthetic.parsing_batch(B, seed=2021)
 g = torch.Generator().manual_seed(3)
 top = None
 imgs = {}
-for name, env in (('split', '1'), ('fp32', '0')):
+from text2human_amd import _lib  # noqa: E402
+for name, env, tile in (('split', '1', 0), ('s128', '1', 128), ('s256', '1', 256), ('fp32', '0', 0)):
     os.environ['T2H_SPLIT_CONV'] = env
+    _lib.load().t2h_conv_split_force_tile(tile)
     model = SampleFromParsingModel(opt, state_dicts=sds)
     model.feed_data(batch)
     if top is None:
@@ -41,4 +43,6 @@ for name, env in (('split', '1'), ('fp32', '0')):
     imgs[name] = img
     gf = (2380.0 if up else 562.88) + 2.19
     print(f'{name:5s}: {ms:7.2f} ms per batch of {B} = {ms / B:6.2f} ms/image = {gf * B / ms:6.1f} TFLOP/s (fp32-equivalent)')
+_lib.load().t2h_conv_split_force_tile(0)
+print(f'max |s256 - s128|: {(imgs["s256"] - imgs["s128"]).abs().max().item():.2e}')
 print(f'max |split - fp32| over the images: {(imgs["split"] - imgs["fp32"]).abs().max().item():.2e}')
