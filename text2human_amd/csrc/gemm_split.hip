@@ -24,6 +24,8 @@
 // free.  Main loop = the same two-register-set, counted-vmcnt software pipeline as
 // the fp32 kernel (gemm.hip): staged pieces are written to LDS and re-issued in the
 // shadow of the MFMAs.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -45,6 +47,15 @@ __device__ __forceinline__ void gload16_async(u32x4& dst, const char* ptr) {
   asm volatile("" : "=v"(dst) : "v"(ptr));
 #else
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+#endif
+}
+// the same with an SGPR base and a 32-bit VGPR offset: half the address registers per issue and no
+// 64-bit vector address arithmetic in the loop (measured on the 256x128 loop: -10 %)
+__device__ __forceinline__ void gload16_async(u32x4& dst, unsigned voff, const char* sbase) {
+#ifdef T2H_SDBG_NOGLOAD
+  asm volatile("" : "=v"(dst) : "v"(voff), "s"(sbase));
+#else
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 #endif
 }
 template <int N>
@@ -107,6 +118,15 @@ __device__ __forceinline__ f32x4 gelu_erf_v(f32x4 v) {
   return f32x4{a[0], a[1], b[0], b[1]};
 }
 
+// T2H_SDBG_HOTLOAD (timing tool only): every workgroup loads the operands of tile (0, 0) -- all L2 hits
+#ifdef T2H_SDBG_HOTLOAD
+#define LM0 0
+#define LN0 0
+#else
+#define LM0 m0
+#define LN0 n0
+#endif
+
 #ifdef T2H_GEMM_TIMING
 __device__ long long* g1_timing = nullptr;  // debug builds only (tools/gemm_phase_timing.py)
 #define G1_MARK(i) do { if (g1_timing && threadIdx.x == 0) g1_timing[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
@@ -119,7 +139,15 @@ __device__ long long* g1_timing = nullptr;  // debug builds only (tools/gemm_pha
 // g takes tiles 2s + g); the partial sums meet in LDS in the epilogue, group 0 first, so
 // the result is deterministic.  It gives a tile that only fills the chip at one block
 // per CU (N = 512 at M = 4096) two waves per SIMD without shrinking the wave tile.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS>
+//
+// PP = 1 ("ping-pong", 8 waves, KS = 1): the two waves that share a SIMD (w and w + 4) run the
+// SAME loop one phase apart -- [read the K tile's fragments from LDS] barrier [its matrix
+// instructions, with the staging stores of a later tile behind them] barrier -- so each SIMD's
+// matrix pipe always has one wave in its matrix phase while the partner's LDS reads are in
+// flight.  In the plain loop all eight waves leave the barrier together, read together and wait
+// for the same fragments: its 256x128 main loop took 1.3 us per K step against 0.77 us of matrix
+// instructions.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int PP>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p, int* const ovf) {
   constexpr int NT = 64 * WARPS_M * WARPS_N;  // threads per K group
   constexpr int NWG = WARPS_M * WARPS_N;      // waves per K group
@@ -138,7 +166,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   constexpr int OT_LD = WM + 4;                  // transposed staging (value planes): floats per column
   constexpr int OW = WM * O_LD > WN * OT_LD ? WM * O_LD : WN * OT_LD;  // staging floats per wave
   constexpr int EPI_B = OW * 4 * NWG * KS;
-  constexpr int MAIN_B = 2 * BUF_B * KS;
+  constexpr int TILE_IMG_B = (BM + BN) * SP_TILE_B;  // PP = 2: unpadded tile image (LDS-DMA), three buffers
+  constexpr int MAIN_B = PP == 2 ? 3 * TILE_IMG_B : 2 * BUF_B * KS;
   constexpr int SMEM_B = MAIN_B > EPI_B ? MAIN_B : EPI_B;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
@@ -176,23 +205,275 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
-  {  // (scope: the staging registers and addresses are dead before the epilogue -- without it the
+  if constexpr (PP == 2) {
+    // ---- ping-pong + LDS-DMA: global_load_lds_dwordx4 writes the K tiles straight into LDS (no
+    // staging registers, no ds_write pass).  A DMA instruction fills 1 KiB = 8 rows x 128 B
+    // lane-linearly, so the image is unpadded; the 16-byte fragment reads stay conflict free through
+    // an XOR swizzle applied on the DMA's SOURCE address and on the read address: logical piece c of
+    // row r lives at piece c ^ ((r >> 1) & 7).  Three tile buffers; phases as in PP = 1 (group 1 one
+    // phase late).  A wave reading tile j requests its 8-row groups of tile j + 2 into the buffer tile
+    // j - 1 left (last read two / one phases ago).  Its pieces of tile j + 1 must have landed before
+    // the barrier in front of phase 2j + 2: group 0 checks at the end of its matrix phase (1.5 steps
+    // after the request), group 1 at the end of its read phase (1 step).
+    static_assert(KS == 1 && NWG == 8 && (BM + BN) % 64 == 0, "ping-pong DMA: 8 waves, whole 8-row groups per wave");
+    constexpr int NL = (BM + BN) / 64;  // DMA instructions per wave and K tile
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    auto pp_barrier = [] {
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef T2H_SDBG_NOBAR
+      __builtin_amdgcn_s_barrier();
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    // SGPR base (advanced by one K tile per request round, scalar) + a 32-bit VGPR offset that never
+    // changes: half the address registers a 64-bit VGPR address moves at every issue, no vector
+    // address arithmetic in the loop (the host checks that the operands span < 2 GiB)
+    unsigned goff[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int g = wave + 8 * i;  // 8-row group of the tile image
+      const int r = g * 8 + (lane >> 3), pc = (lane & 7) ^ ((r >> 1) & 7);
+      const bool isA = r < BM;
+      const int grow = isA ? min(LM0 + r, p.M - 1) : min(LN0 + r - BM, p.N - 1);
+      goff[i] = (unsigned)grow * (unsigned)row_b + pc * 16;
+    }
+    static_assert(BM % 64 == 0, "an 8-row group belongs to one operand");
+    const unsigned wdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+    auto dma = [&](int kt, unsigned buf_off) {  // buf_off: byte offset of the tile buffer (scalar)
+      const int64_t k0 = (int64_t)min(kt, last) * SP_TILE_B;
+      const char* const baseA = reinterpret_cast<const char*>(p.A) + k0;
+      const char* const baseB = reinterpret_cast<const char*>(p.B) + k0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+#ifndef T2H_SDBG_NOGLOAD
+        unsigned keep;
+#ifdef T2H_SDBG_HALFDMA
+        if (i & 1) continue;
+#endif
+        const char* const base = i < BM / 64 ? baseA : baseB;  // rows 64 i + 8 wave ..: one operand per i
+        const unsigned dst_i = wdst + buf_off + i * 8192;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(goff[i]), "s"(base), "s"(dst_i)
+                     : "memory");
+#endif
+      }
+    };
+    auto wait_landed = [&] {  // everything but the NL youngest requests
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // fragment read offsets inside a tile image: row * 128 + ((plane * 4 + u * 2 + hh) ^ swizzle) * 16
+    const int swz = (l31 >> 1) & 7;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {
+      const int pcs = ((c2 * 2 + hh) ^ swz) * 16;
+      offA[c2] = (wm0 + l31) * 128 + pcs;
+      offB[c2] = (BM + wn0 + l31) * 128 + pcs;
+    }
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+    constexpr int PC[3] = {1, 1, 0};
+    dma(0, 0);
+    dma(1, TILE_IMG_B);
+    wait_landed();  // tile 0
+    pp_barrier();
+    G1_MARK(1);
+    if (grp == 1) pp_barrier();  // phase 0 belongs to group 0
+    unsigned b_cur = 0, b_nxt = TILE_IMG_B, b_free = 2 * TILE_IMG_B;  // buffers of tiles kt, kt + 1, kt + 2
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* img = smem + b_cur;
+      f16x8 af[2][TM][2], bfr[2][TN][2];
+#ifdef T2H_SDBG_DMAFIRST
+      dma(kt + 2, b_free);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#ifdef T2H_SDBG_NOFRAG
+            asm volatile("" : "=v"(af[u][ti][pl]) : "v"(img));
+#else
+            af[u][ti][pl] = *reinterpret_cast<const f16x8*>(img + ti * 32 * 128 + offA[pl * 2 + u]);
+#endif
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#ifdef T2H_SDBG_NOFRAG
+            asm volatile("" : "=v"(bfr[u][tj][pl]) : "v"(img));
+#else
+            bfr[u][tj][pl] = *reinterpret_cast<const f16x8*>(img + tj * 32 * 128 + offB[pl * 2 + u]);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef T2H_SDBG_DMAFIRST
+      dma(kt + 2, b_free);
+#endif
+      if (grp == 1) wait_landed();  // tile kt + 1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pp_barrier();
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TN; ++tj) {
+#ifdef T2H_SDBG_NOMMA
+              asm volatile("" : "+v"(acc[PC[t]][ti][tj]) : "v"(af[u][ti][PA[t]]), "v"(bfr[u][tj][PB[t]]));
+#else
+              acc[PC[t]][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][ti][PA[t]], bfr[u][tj][PB[t]],
+                                                                           acc[PC[t]][ti][tj], 0, 0, 0);
+#endif
+            }
+      if (grp == 0) wait_landed();  // tile kt + 1
+      pp_barrier();
+      const unsigned t = b_cur;
+      b_cur = b_nxt;
+      b_nxt = b_free;
+      b_free = t;
+    }
+    if (grp == 0) pp_barrier();  // group 1's last matrix phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead requests too, before
+    __syncthreads();                                  // the tile buffers are reused by the epilogue
+  } else if constexpr (PP == 1) {
+    static_assert(KS == 1 && NWG == 8, "ping-pong: 8 waves, no K split");
+    static_assert(PIECES % NT == 0, "ping-pong: whole pieces per thread");
+    // waves w and w + 4 share a SIMD; group 1 runs one phase late
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    // (the fences keep the compiler from moving matrix instructions or LDS reads into the partner's phase)
+    auto pp_barrier = [] {
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef T2H_SDBG_NOBAR
+      __syncthreads();
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    static_assert((BM * SP_PIECES) % NT == 0, "each round of pieces belongs to one operand");
+    constexpr int LA = BM * SP_PIECES / NT;
+    unsigned src[L];
+    int dst[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const int q = tid + NT * i;
+      const int row = q / SP_PIECES, pc = q - row * SP_PIECES;
+      const bool isA = i < LA;
+      const int grow = isA ? min(LM0 + row, p.M - 1) : min(LN0 + row - BM, p.N - 1);
+      src[i] = (unsigned)grow * (unsigned)row_b + pc * 16;
+      dst[i] = row * SP_LDS_ROW + pc * 16;
+    }
+    const char* const gA = reinterpret_cast<const char*>(p.A);
+    const char* const gB = reinterpret_cast<const char*>(p.B);
+    u32x4 rg[L];  // ONE register set: a piece is re-requested right after it went to LDS
+    // piece q of the staged tile -> LDS buffer `buf`, then request it for K tile `kt_next`.  The L
+    // requests of a tile are issued oldest first, so L - 1 younger ones are outstanding whenever
+    // piece q is waited for.
+    auto restage = [&](int q, int buf, int kt_next) {
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vmcnt16<L - 1>(rg[q]);
+#ifdef T2H_SDBG_NOPUT
+      asm volatile("" ::"v"(rg[q]), "v"(dst[q] + buf));
+#else
+      *reinterpret_cast<u32x4*>(smem + buf * BUF_B + dst[q]) = rg[q];
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      gload16_async(rg[q], src[q], (q < LA ? gA : gB) + (int64_t)min(kt_next, last) * K_STEP_B);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // Who writes what when.  Phase 2t: group 0 reads tile t's fragments; 2t + 1: group 0 computes
+    // tile t and group 1 reads it; 2t + 2: group 1 computes it.  Tile t + 2 shares tile t's buffer, may
+    // be written from phase 2t + 2 on and must be complete by the end of phase 2t + 3: exactly the two
+    // phases in which the groups read tile t + 1.  So the staging stores go into the READ phase (a wave
+    // reading tile j stores its pieces of tile j + 1 and requests tile j + 2) and the matrix phase is
+    // nothing but matrix instructions: a ds_write_b128 between them held the issuing wave for the
+    // store path's 13 cycles times however many waves stored at once, and the matrix pipe with it
+    // (removing the stores took the 16-step loop from 21 to 14.4 us; all data movement, to 13.1).
+#pragma unroll
+    for (int i = 0; i < L; ++i) gload16_async(rg[i], src[i], i < LA ? gA : gB);
+#pragma unroll
+    for (int q = 0; q < L; ++q) restage(q, 0, 1);
+    pp_barrier();
+    G1_MARK(1);
+    if (grp == 1) pp_barrier();  // phase 0 belongs to group 0
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+    constexpr int PC[3] = {1, 1, 0};
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* Ab = smem + (kt & 1) * BUF_B + (wm0 + l31) * SP_LDS_ROW + hh * 16;
+      const char* Bb = smem + (kt & 1) * BUF_B + (BM + wn0 + l31) * SP_LDS_ROW + hh * 16;
+      f16x8 af[2][TM][2], bfr[2][TN][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#ifdef T2H_SDBG_NOFRAG
+            asm volatile("" : "=v"(af[u][ti][pl]) : "v"(Ab));
+#else
+            af[u][ti][pl] = *reinterpret_cast<const f16x8*>(Ab + ti * 32 * SP_LDS_ROW + pl * 64 + u * 32);
+#endif
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#ifdef T2H_SDBG_NOFRAG
+            asm volatile("" : "=v"(bfr[u][tj][pl]) : "v"(Bb));
+#else
+            bfr[u][tj][pl] = *reinterpret_cast<const f16x8*>(Bb + tj * 32 * SP_LDS_ROW + pl * 64 + u * 32);
+#endif
+      }
+#pragma unroll
+      for (int q = 0; q < L; ++q) restage(q, (kt + 1) & 1, kt + 2);
+      pp_barrier();
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TN; ++tj) {
+#ifdef T2H_SDBG_NOMMA
+              asm volatile("" : "+v"(acc[PC[t]][ti][tj]) : "v"(af[u][ti][PA[t]]), "v"(bfr[u][tj][PB[t]]));
+#else
+              acc[PC[t]][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][ti][PA[t]], bfr[u][tj][PB[t]],
+                                                                           acc[PC[t]][ti][tj], 0, 0, 0);
+#endif
+            }
+      pp_barrier();
+    }
+    if (grp == 0) pp_barrier();  // group 1's last matrix phase
+#pragma unroll
+    for (int i = 0; i < L; ++i) wait_vmcnt16<0>(rg[i]);
+  } else {  // (scope: the staging registers and addresses are dead before the epilogue -- without it the
      // register allocator of ROCm 7.2 spilled 423 registers in the 256x128 instantiation)
   // ---- per-thread staging slots (fixed for the whole kernel).  Rows beyond M / N are
   // loaded from a clamped (valid) address and NOT masked: an output element depends only
   // on its own A row and B row, and rows / columns beyond the problem are never stored.
-  const char* src[L];
+  static_assert(PIECES % NT == 0 && (BM * SP_PIECES) % NT == 0, "whole rounds of pieces, each of one operand");
+  constexpr int LA = BM * SP_PIECES / NT;  // rounds i < LA stage A rows, the others B rows
+  unsigned src[L];  // byte offset into the operand (the host checks it spans < 2 GiB)
   int dst[L];
 #pragma unroll
   for (int i = 0; i < L; ++i) {
-    int q = tid + NT * i;
-    if (q >= PIECES) q -= PIECES;
+    const int q = tid + NT * i;
     const int row = q / SP_PIECES, pc = q - row * SP_PIECES;  // row in [0, BM + BN)
-    const bool isA = row < BM;
-    const int grow = isA ? min(m0 + row, p.M - 1) : min(n0 + row - BM, p.N - 1);
-    src[i] = reinterpret_cast<const char*>(isA ? p.A : p.B) + (int64_t)grow * row_b + kg * SP_TILE_B + pc * 16;
+    const bool isA = i < LA;
+    const int grow = isA ? min(LM0 + row, p.M - 1) : min(LN0 + row - BM, p.N - 1);
+    src[i] = (unsigned)grow * (unsigned)row_b + kg * SP_TILE_B + pc * 16;
     dst[i] = row * SP_LDS_ROW + pc * 16;
   }
+  const char* const gA = reinterpret_cast<const char*>(p.A);
+  const char* const gB = reinterpret_cast<const char*>(p.B);
   u32x4 rg[2][L];
 #ifdef T2H_SDBG_NOPUT
   auto put = [&](int i, const u32x4& r, int buf) { asm volatile("" ::"v"(r), "v"(dst[i] + buf)); };
@@ -203,7 +484,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     constexpr int S = decltype(setc)::value;
     const int64_t k0 = (int64_t)min(kt, last) * K_STEP_B;
 #pragma unroll
-    for (int i = 0; i < L; ++i) gload16_async(rg[S][i], src[i] + k0);
+    for (int i = 0; i < L; ++i) gload16_async(rg[S][i], src[i], (i < LA ? gA : gB) + k0);
   };
 
   using set0 = std::integral_constant<int, 0>;
@@ -277,7 +558,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
               wait_vmcnt16<2 * L - 1>(rg[S][q]);
               put(q, rg[S][q], buf ^ 1);
               __builtin_amdgcn_sched_barrier(0);
-              gload16_async(rg[S][q], src[q] + kn);
+              gload16_async(rg[S][q], src[q], (q < LA ? gA : gB) + kn);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -437,22 +718,29 @@ __global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t
   t2h_store_split4(out, row, C, c0, *reinterpret_cast<const f32x4*>(x + row * ldx + c0), ovf);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1, int PP = 0>
 int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE(a.K % (32 * KS) == 0, "t2h_gemm_split_f32: this tile config needs K %% %d == 0", 32 * KS);
   if (a.Vt)
     T2H_REQUIRE(a.vt_col0 % BN == 0, "t2h_gemm_split_f32: vt_col0=%d must be a multiple of the %d-column tile",
                 a.vt_col0, BN);
+  T2H_REQUIRE((int64_t)(a.M > a.N ? a.M : a.N) * a.K * 4 < (int64_t(1) << 31),
+              "t2h_gemm_split_f32: operands are addressed with 32-bit byte offsets (each must span < 2 GiB)");
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
   int* ovf = t2h_split_overflow_flag_ptr();
   T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS>), grid,
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP>), grid,
                      dim3(64 * WARPS_M * WARPS_N * KS), 0, s, a, ovf);
   T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
   return T2H_OK;
 }
 
 int g_force_split_cfg = -1;
+
+bool pp_default() {
+  static const bool on = !(getenv("T2H_GEMM_SPLIT_PP") && atoi(getenv("T2H_GEMM_SPLIT_PP")) == 0);
+  return on;
+}
 
 }  // namespace
 
@@ -498,7 +786,9 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     else if (tiles128 >= 1024) cfg = 1;
     else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
     else if (a.N % 128 == 0 && a.M % 256 == 0 && tiles128 / 2 >= 192 && tiles128 / 2 <= 256)
-      cfg = 4;  // qkv / fc1 at M = 4096: 192 / 256 tiles of 256x128, at most one per CU
+      // qkv / fc1 at M = 4096: 192 / 256 tiles of 256x128, at most one per CU; the ping-pong LDS-DMA
+      // loop (8) is 5-6 % faster than the register-staged one (4; T2H_GEMM_SPLIT_PP=0 for the A/B)
+      cfg = pp_default() ? 8 : 4;
     else cfg = 0;
   }
   switch (cfg) {
@@ -508,6 +798,8 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     case 4: return launch_split<256, 128, 4, 2>(a, s);  // 8 waves, wave tile 64x64
     case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
     case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
+    case 7: return launch_split<256, 128, 4, 2, 1, 1>(a, s);  // 8 waves, wave tile 64x64, ping-pong
+    case 8: return launch_split<256, 128, 4, 2, 1, 2>(a, s);  // the same with LDS-DMA staging
     default: return launch_split<128, 64, 2, 2>(a, s);  // 4 waves, wave tile 64x32
   }
 }

@@ -19,16 +19,21 @@ from text2human_amd._lib import GemmSplitArgs  # noqa: E402
 
 csrc = os.path.join(ROOT, 'text2human_amd', 'csrc')
 so = '/tmp/libt2h_gemm_timing.so'
+DEFS = [d for d in os.environ.get('T2H_TIMING_DEFS', '').split(',') if d]  # e.g. T2H_SDBG_NOPUT,T2H_SDBG_NOGLOAD
 subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-comment',
-                f'-I{ROOT}/include', '-DT2H_GEMM_TIMING', os.path.join(csrc, 'api.hip'),
+                f'-I{ROOT}/include', '-DT2H_GEMM_TIMING', *[f'-D{d}' for d in DEFS], os.path.join(csrc, 'api.hip'),
                 os.path.join(csrc, 'gemm_split.hip'), '-o', so], check=True)
 lib = ctypes.CDLL(so)
 CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 else [4, 6]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 M = 512 * B
 g0 = torch.Generator().manual_seed(0)
+SHAPES = os.environ.get('T2H_TIMING_SHAPES', 'fc1,qkv_nov,proj,fc2').split(',')
+print('defs:', DEFS or 'none', flush=True)
 for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536, 512, False, False),
                                     proj=(512, 512, False, True), fc2=(512, 2048, False, True)).items():
+    if name not in SHAPES:
+        continue
     a = (torch.randn(M * k * 2, generator=g0) * 0.5).half().view(torch.int16).cuda()
     w = (torch.randn(n * k * 2, generator=g0) * 0.05).half().view(torch.int16).cuda()
     out = torch.zeros(M, n, device='cuda')
