@@ -137,6 +137,20 @@ typedef struct t2h_gemm_split_args {
    * P*V matrix instruction contracts them.  NULL = off. */
   uint16_t* Vt;
   int32_t vt_col0, vt_T, vt_hd;
+  /* LayerNorm folded into the two Linears either side of it (transformer_arch.py:93-95: x + mlp(ln2(x)),
+   * x + attn(ln1(x))): no LayerNorm launch, no normalised copy of the activations.
+   *   producer (proj / fc2, which write the residual stream x): ln_part_out[M][N/32][2] receives, per row
+   *     and 32-column slice of the FINAL output values, (mean, sum of squared deviations from that mean);
+   *     C_split then carries split(x) for the consumer.  Needs N % 32 == 0, not combined with Vt.
+   *   consumer (q|k|v / fc1 with B = W diag(gamma), bias = b + W beta, both folded on the host):
+   *     ln_part_in[M][K/32][2] are the partials of A's rows (A = split(x), NOT normalised),
+   *     ln_colsum[N] = sum_k B[n][k] of the split-rounded weights; the epilogue evaluates
+   *     rstd_m (acc[m][n] - mean_m ln_colsum[n]) + bias[n] with (mean, rstd) from a fixed-order
+   *     (Chan) combination of the row's partials, eps = ln_eps.  NULL = off. */
+  float* ln_part_out;
+  const float* ln_part_in;
+  const float* ln_colsum;
+  float ln_eps;
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);

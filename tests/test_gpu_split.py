@@ -185,3 +185,76 @@ def test_last_layer_tail_on_the_changed_rows_only_matches_the_full_evaluation():
     net.hidden(*args, defer_tail=True)                     # too many rows: the tail runs on all of them
     got, compact = net.finish_tail(rows, 1000)
     assert not compact and torch.equal(got, full)
+
+
+def test_sampler_stack_with_folded_layernorm(monkeypatch):
+    """T2H_FOLD_LN=1: the 3-layer stack without LayerNorm launches (except layer 0's ln1) agrees with the
+    default one to the activation tolerance, full and with the last layer's tail on compact rows."""
+    sd = synthetic.fill(synthetic.transformer_schema(18432, 1024, 18, 512, 3, 512, 18), seed=12)
+    gen = torch.Generator().manual_seed(22)
+    args = tuple(torch.randint(0, hi, (2, 512), generator=gen).to(DEV) for hi in (18433, 1024, 18))
+    P0 = weights.Params(DEV)
+    ref = engine.SamplerNet(P0, weights.pack_transformer(P0, sd, 'tf'), 8, 'tf', split=True).hidden(*args).clone()
+    monkeypatch.setenv('T2H_FOLD_LN', '1')
+    P = weights.Params(DEV)
+    net = engine.SamplerNet(P, weights.pack_transformer(P, sd, 'tf'), 8, 'tf', split=True)
+    assert net.fold_ln
+    full = net.hidden(*args).clone()
+    assert (full - ref).abs().max().item() < 2e-4, (full - ref).abs().max().item()
+    rows = torch.randperm(1024, generator=gen)[:29].to(torch.int32).to(DEV)
+    net.hidden(*args, defer_tail=True)
+    got, compact = net.finish_tail(rows, 29)
+    assert compact and (got - full[rows.long()]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('M', [4096, 48])
+def test_folded_layernorm_producer_and_consumer(M):
+    """t2h_gemm_split_args.ln_part_*: the producer's row partials and split(x) are those of its fp32
+    output; the consumer on split(x) with gamma folded into W equals Linear(LayerNorm(x)) as closely as
+    the LayerNorm kernel + the plain split GEMM do."""
+    from text2human_amd import weights
+    C, N = 512, 1536
+    y, wp, bp = _rnd(M, C, seed=40) * 1.2, _rnd(C, C, seed=41, scale=0.05), _rnd(C, seed=42)
+    res = _rnd(M, C, seed=43) * 3.0 + 0.7 + _rnd(M, 1, seed=44)      # rows with their own offset and spread
+    x = torch.empty(M, C, device=DEV)
+    xs, part = ops.split_rows_empty(M, C, DEV), ops.ln_partials_empty(M, C, DEV)
+    ops.gemm_split(ops.split_rows(y.to(DEV)), ops.pack_split_rows_host(wp).to(DEV), M, C, C, out=x, bias=bp.to(DEV),
+                   residual=res.to(DEV), out_split=xs, ln_part_out=part)
+    x_plain = torch.empty(M, C, device=DEV)
+    ops.gemm_split(ops.split_rows(y.to(DEV)), ops.pack_split_rows_host(wp).to(DEV), M, C, C, out=x_plain,
+                   bias=bp.to(DEV), residual=res.to(DEV))
+    assert torch.equal(x, x_plain)                                    # the extra outputs change nothing
+    assert torch.equal(xs.view(-1), ops.split_rows(x).view(-1))       # split(x), bitwise
+    xc = x.cpu().double().view(M, C // 32, 32)
+    mu = xc.mean(-1)
+    m2 = ((xc - mu[..., None]) ** 2).sum(-1)
+    pc = part.cpu().double()
+    assert (pc[..., 0] - mu).abs().max() < 1e-5 and ((pc[..., 1] - m2).abs() <= 1e-4 + 1e-5 * m2).all()
+    # consumer
+    w, b = _rnd(N, C, seed=45, scale=0.06), _rnd(N, seed=46)
+    g, beta = _rnd(C, seed=47) * 0.2 + 1.0, _rnd(C, seed=48) * 0.3
+    ref = F.layer_norm(x.cpu().double(), (C, ), g.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
+    wf_split, cs, bf = weights.fold_layernorm(w, b, g, beta)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm_split(xs, wf_split.to(DEV), M, N, C, out=out, bias=bf.to(DEV), ln_in=(part, cs.to(DEV)))
+    err_f = (out.cpu().double() - ref).abs()
+    hs = ops.split_rows_empty(M, C, DEV)
+    ops.layernorm_split(x, g.to(DEV), beta.to(DEV), hs)
+    out_p = torch.empty(M, N, device=DEV)
+    ops.gemm_split(hs, ops.pack_split_rows_host(w).to(DEV), M, N, C, out=out_p, bias=b.to(DEV))
+    err_p = (out_p.cpu().double() - ref).abs()
+    assert (err_f <= 2e-5 + 2e-5 * ref.abs()).all(), err_f.max().item()
+    assert err_f.max().item() <= 3 * err_p.max().item() + 1e-6, (err_f.max().item(), err_p.max().item())
+    if M % 512 == 0:  # the q|k|v form: q, k as split rows, v as transposed planes
+        B, H, T = M // 512, 8, 512
+        qks, vt = ops.split_rows_empty(M, N, DEV), ops.vt_empty(B, H, T, DEV)
+        ops.gemm_split(xs, wf_split.to(DEV), M, N, C, out_split=qks, bias=bf.to(DEV), ln_in=(part, cs.to(DEV)),
+                       vt=vt, vt_col0=2 * C, vt_T=T, vt_hd=64)
+        qks_p, vt_p = ops.split_rows_empty(M, N, DEV), ops.vt_empty(B, H, T, DEV)
+        ops.gemm_split(ops.split_rows(out), ops.pack_split_rows_host(torch.eye(N)).to(DEV), M, N, N, out_split=qks_p,
+                       vt=vt_p, vt_col0=2 * C, vt_T=T, vt_hd=64)       # identity GEMM: the same values, routed
+        a, b2 = ops.unsplit_rows_host(qks, M, N)[:, :2 * C], ops.unsplit_rows_host(qks_p, M, N)[:, :2 * C]
+        assert (a - b2).abs().max() < 1e-5
+        va = vt.cpu().view(torch.float16).float()
+        vb = vt_p.cpu().view(torch.float16).float()
+        assert ((va[:, :, 0] + va[:, :, 1] / 2048) - (vb[:, :, 0] + vb[:, :, 1] / 2048)).abs().max() < 1e-5

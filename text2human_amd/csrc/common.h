@@ -78,7 +78,10 @@ __device__ __forceinline__ float fast_exp(float x) {
 template <typename V>
 __device__ __forceinline__ void t2h_store16_wt(void* ptr, const V& v) {
   static_assert(sizeof(V) == 16, "16-byte vector");
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+  // (s_nop 1: a store of more than 8 bytes reads its data registers up to two wait states after it
+  // issues; the compiler's hazard recognizer does not see into the asm and may overwrite them in the
+  // very next instruction -- it did, once code followed the split-row stores of the GEMM epilogue)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
 // ---- split-row helpers shared by the producers of t2h_gemm_split_f32 operands.

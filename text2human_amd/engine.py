@@ -170,6 +170,14 @@ class SamplerNet:
         # split_mha (with split): attention on the fp16 matrix cores too -- the q|k|v
         # projection writes q, k as split rows and v as transposed planes, no fp32 qkv
         self.split_mha = split_mha
+        # fold_ln (T2H_FOLD_LN=1, with split + split_mha; off by default): no LayerNorm launches inside the
+        # stack.  proj / fc2 (the writers of the residual stream) also emit split(x) and per-row partial
+        # moments; q|k|v / fc1 run on split(x) with gamma folded into their weights and apply (mean, rstd)
+        # in the epilogue (t2h_gemm_split_args.ln_part_*).  Layer 0's ln1 (input from the embedding) stays
+        # a kernel.  Measured at B=8: the 46 LayerNorm launches it removes per step (5.1 us each) are paid
+        # back almost entirely by the four GEMMs (+1.5 .. +5 us each): 816 vs 818-826 ms per batch.
+        self.fold_ln = (split and split_mha and os.environ.get('T2H_FOLD_LN', '0') == '1'
+                        and f'{name}.0.fc1.wf_split' in P)
         self._buf = {}
 
     def _buffers(self, M, C, dev):
@@ -180,6 +188,7 @@ class SamplerNet:
                                    h_split=ops.split_rows_empty(M, C, dev), y_split=ops.split_rows_empty(M, C, dev),
                                    u_split=ops.split_rows_empty(M, 4 * C, dev),
                                    qk_split=ops.split_rows_empty(M, 3 * C, dev),
+                                   x_split=ops.split_rows_empty(M, C, dev), ln_part=ops.ln_partials_empty(M, C, dev),
                                    vt=ops.vt_empty(M // 512 if M % 512 == 0 else 1, self.n_head, 512, dev))}
         return self._buf[key]
 
@@ -214,20 +223,39 @@ class SamplerNet:
             Bs = B // ns
             sl = [(j * Bs * T, (j + 1) * Bs * T, j * Bs, (j + 1) * Bs) for j in range(ns)]
 
+            fold = self.fold_ln and ns == 1
+            xsp, part = buf['x_split'], buf['ln_part']
+            L = self.desc['n_layers']
+
             def layer(i, lo, hi, b0, b1, tail=True):
                 p = f'{nm}.{i}'
                 m, xs = hi - lo, x[lo:hi]
-                ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])
-                if self.split_mha:
-                    ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out_split=qks[lo:hi],
-                                   bias=P[f'{p}.qkv.b'], vt=vt[b0:b1], vt_col0=2 * C, vt_T=T,
-                                   vt_hd=C // self.n_head)
-                    ops.mha_split(qks[lo:hi], 3 * C, vt[b0:b1], b1 - b0, T, self.n_head, out_split=ys[lo:hi])
+                if fold and i > 0:  # split(x) and its row moments came with the previous layer's fc2
+                    ops.gemm_split(xsp, P[f'{p}.qkv.wf_split'], m, 3 * C, C, out_split=qks, bias=P[f'{p}.qkv.bf'],
+                                   vt=vt, vt_col0=2 * C, vt_T=T, vt_hd=C // self.n_head,
+                                   ln_in=(part, P[f'{p}.qkv.cs']))
+                    ops.mha_split(qks, 3 * C, vt, B, T, self.n_head, out_split=ys)
                 else:
-                    ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out=qkv[lo:hi],
-                                   bias=P[f'{p}.qkv.b'])
-                    ops.mha_noncausal_split(qkv[lo:hi], b1 - b0, T, self.n_head, ys[lo:hi])
+                    ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])
+                    if self.split_mha:
+                        ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out_split=qks[lo:hi],
+                                       bias=P[f'{p}.qkv.b'], vt=vt[b0:b1], vt_col0=2 * C, vt_T=T,
+                                       vt_hd=C // self.n_head)
+                        ops.mha_split(qks[lo:hi], 3 * C, vt[b0:b1], b1 - b0, T, self.n_head, out_split=ys[lo:hi])
+                    else:
+                        ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out=qkv[lo:hi],
+                                       bias=P[f'{p}.qkv.b'])
+                        ops.mha_noncausal_split(qkv[lo:hi], b1 - b0, T, self.n_head, ys[lo:hi])
                 if not tail:
+                    return
+                if fold:
+                    ops.gemm_split(ys, P[f'{p}.proj.w_split'], m, C, C, out=x, bias=P[f'{p}.proj.b'], residual=x,
+                                   out_split=xsp, ln_part_out=part)
+                    ops.gemm_split(xsp, P[f'{p}.fc1.wf_split'], m, 4 * C, C, out_split=us, bias=P[f'{p}.fc1.bf'],
+                                   act=ACT_GELU, ln_in=(part, P[f'{p}.fc1.cs']))
+                    nxt = i + 1 < L  # the last layer's output only feeds ln_f in the sampling tail
+                    ops.gemm_split(us, P[f'{p}.fc2.w_split'], m, C, 4 * C, out=x, bias=P[f'{p}.fc2.b'], residual=x,
+                                   out_split=xsp if nxt else None, ln_part_out=part if nxt else None)
                     return
                 ops.gemm_split(ys[lo:hi], P[f'{p}.proj.w_split'], m, C, C, out=xs, bias=P[f'{p}.proj.b'],
                                residual=xs)
@@ -239,7 +267,6 @@ class SamplerNet:
 
             self._deferred = None
             if ns == 1:
-                L = self.desc['n_layers']
                 for i in range(L - 1):
                     layer(i, *sl[0])
                 layer(L - 1, *sl[0], tail=not defer_tail)
@@ -285,9 +312,17 @@ class SamplerNet:
             m, xc, yc, compact = M, x, ys, False
             buf = self._buffers(M, C, x.device)
             hc, uc = buf['h_split'], buf['u_split']
-        ops.gemm_split(yc, P[f'{p}.proj.w_split'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc)
-        ops.layernorm_split(xc, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hc)
-        ops.gemm_split(hc, P[f'{p}.fc1.w_split'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.b'], act=ACT_GELU)
+        if self.fold_ln:
+            pc = ops.ln_partials_empty(m, C, x.device) if compact else self._buffers(M, C, x.device)['ln_part']
+            ops.gemm_split(yc, P[f'{p}.proj.w_split'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc,
+                           out_split=hc, ln_part_out=pc)
+            ops.gemm_split(hc, P[f'{p}.fc1.wf_split'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.bf'],
+                           act=ACT_GELU, ln_in=(pc, P[f'{p}.fc1.cs']))
+        else:
+            ops.gemm_split(yc, P[f'{p}.proj.w_split'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc)
+            ops.layernorm_split(xc, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hc)
+            ops.gemm_split(hc, P[f'{p}.fc1.w_split'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.b'],
+                           act=ACT_GELU)
         ops.gemm_split(uc, P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xc, bias=P[f'{p}.fc2.b'], residual=xc)
         return xc, compact
 

@@ -306,14 +306,21 @@ def pack_split_rows_host(w):
     return planes.view(torch.int16)
 
 
+def ln_partials_empty(M, C, device):
+    """Per (row, 32-column slice) (mean, M2) partials of a [M, C] tensor (t2h_gemm_split_args.ln_part_out)."""
+    return torch.empty(M, C // 32, 2, dtype=torch.float32, device=device)
+
+
 def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE,
-               vt=None, vt_col0=0, vt_T=0, vt_hd=64):
+               vt=None, vt_col0=0, vt_T=0, vt_hd=64, ln_part_out=None, ln_in=None, ln_eps=1e-5):
     """C = act(A @ W^T + bias) + residual on the fp16 matrix cores at fp32-class
     accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
     split-row form `out_split` of the result.  With `vt` the output columns from
     `vt_col0` on go to the transposed value planes of mha_split instead
-    (t2h_gemm_split_args.Vt)."""
-    _chk_f32(out, bias, residual)
+    (t2h_gemm_split_args.Vt).  Folded LayerNorm (include/t2h_hip.h): `ln_part_out` receives the row
+    partials of the result; `ln_in=(partials of A's rows, column sums of W)` makes the epilogue
+    evaluate rstd (acc - mean colsum) + bias, i.e. LayerNorm(A) @ W0^T for W = W0 diag(gamma)."""
+    _chk_f32(out, bias, residual, ln_part_out)
     g = _lib.GemmSplitArgs()
     g.A, g.B = a_split.data_ptr(), w_split.data_ptr()
     g.C = out.data_ptr() if out is not None else None
@@ -326,6 +333,14 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     g.epi_act = act
     if vt is not None:
         g.Vt, g.vt_col0, g.vt_T, g.vt_hd = vt.data_ptr(), vt_col0, vt_T, vt_hd
+    if ln_part_out is not None:
+        assert tuple(ln_part_out.shape) == (M, N // 32, 2), ln_part_out.shape
+        g.ln_part_out = ln_part_out.data_ptr()
+    if ln_in is not None:
+        part, colsum = ln_in
+        _chk_f32(part, colsum)
+        assert tuple(part.shape) == (M, K // 32, 2) and colsum.numel() == N, (part.shape, colsum.shape)
+        g.ln_part_in, g.ln_colsum, g.ln_eps = part.data_ptr(), colsum.data_ptr(), ln_eps
     lib = _lib.load()
     if _prof is not None:
         _prof['count'] += 1
