@@ -21,7 +21,7 @@ csrc = os.path.join(ROOT, 'text2human_amd', 'csrc')
 so = '/tmp/libt2h_gemm_timing.so'
 DEFS = [d for d in os.environ.get('T2H_TIMING_DEFS', '').split(',') if d]  # e.g. T2H_SDBG_NOPUT,T2H_SDBG_NOGLOAD
 subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-comment',
-                f'-I{ROOT}/include', '-DT2H_GEMM_TIMING', *[f'-D{d}' for d in DEFS], os.path.join(csrc, 'api.hip'),
+                f'-I{ROOT}/include', '-DT2H_GEMM_TIMING', *[f'-D{d}' for d in DEFS], *(["-DT2H_DMA_POLICY=\" " + os.environ['T2H_DMA_POLICY'].replace('-', '') + "\""] if os.environ.get('T2H_DMA_POLICY') else []), os.path.join(csrc, 'api.hip'),
                 os.path.join(csrc, 'gemm_split.hip'), '-o', so], check=True)
 lib = ctypes.CDLL(so)
 CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 else [4, 6]
