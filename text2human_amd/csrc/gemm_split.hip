@@ -905,13 +905,16 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     const int64_t tiles64 = (int64_t)((a.M + 127) / 128) * ((a.N + 63) / 64);
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int64_t tiles256 = (int64_t)((a.M + 127) / 128) * ((a.N + 255) / 256);
+    const int64_t tiles_big = (a.M % 256 == 0 && a.N % 128 == 0) ? (int64_t)(a.M / 256) * (a.N / 128) : 0;
     if (a.M <= 64) cfg = 2;
+    else if (tiles_big >= 192)
+      // 256x128 tiles wherever they give (nearly) every CU one: q|k|v / fc1 at M = 4096 (192 / 256
+      // tiles) and every sampler Linear but proj at M = 16384 (q|k|v 99 vs 104 / 126 us for the 128x64 /
+      // 128x128 tiles, fc2 93 vs 111).  The ping-pong LDS-DMA loop (8) is 5-6 % faster than the
+      // register-staged one (4; T2H_GEMM_SPLIT_PP=0 for the A/B)
+      cfg = pp_default() ? 8 : 4;
     else if (tiles128 >= 1024) cfg = 1;
     else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
-    else if (a.N % 128 == 0 && a.M % 256 == 0 && tiles128 / 2 >= 192 && tiles128 / 2 <= 256)
-      // qkv / fc1 at M = 4096: 192 / 256 tiles of 256x128, at most one per CU; the ping-pong LDS-DMA
-      // loop (8) is 5-6 % faster than the register-staged one (4; T2H_GEMM_SPLIT_PP=0 for the A/B)
-      cfg = pp_default() ? 8 : 4;
     else cfg = 0;
   }
   switch (cfg) {

@@ -7,15 +7,19 @@ namespace {
 // (mean, then centred variance) like torch's rowwise moments.
 // SPLIT: the result is written as split rows (two fp16 planes) for the
 // split-precision GEMM instead of fp32.
+#ifndef T2H_LN_RPB
+#define T2H_LN_RPB 8  // rows (= waves) per workgroup: with the input just written by the previous kernel,
+                      // 6.3 us at 8 against 7.3 at 4, 6.6 at 2 / 16 (tools/ln_block_bench.py)
+#endif
 template <int VPL, bool SPLIT = false>  // float4 vectors per lane: C = 256 * VPL
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(64 * T2H_LN_RPB) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         float* __restrict__ y, int rows,
                                                         float eps, int* ovf) {
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * T2H_LN_RPB + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (int64_t)row * C;
   f32x4 v[VPL];
@@ -246,7 +250,7 @@ extern "C" int t2h_layernorm_f32(const float* x, const float* gamma, const float
   T2H_REQUIRE(rows > 0, "t2h_layernorm_f32: rows=%d", rows);
   T2H_REQUIRE(t2h_aligned16(x) && t2h_aligned16(y) && t2h_aligned16(gamma) && t2h_aligned16(beta),
               "t2h_layernorm_f32: 16-byte alignment");
-  dim3 grid((rows + 3) / 4), block(256);
+  dim3 grid((rows + T2H_LN_RPB - 1) / T2H_LN_RPB), block(64 * T2H_LN_RPB);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (C == 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr));
   else if (C == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr));
@@ -266,7 +270,7 @@ extern "C" int t2h_layernorm_split_f32(const float* x, const float* gamma, const
   T2H_REQUIRE(rows > 0, "t2h_layernorm_split_f32: rows=%d", rows);
   T2H_REQUIRE(t2h_aligned16(x) && t2h_aligned16(y_split) && t2h_aligned16(gamma) && t2h_aligned16(beta),
               "t2h_layernorm_split_f32: 16-byte alignment");
-  dim3 grid((rows + 3) / 4), block(256);
+  dim3 grid((rows + T2H_LN_RPB - 1) / T2H_LN_RPB), block(64 * T2H_LN_RPB);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* y = reinterpret_cast<float*>(y_split);
   int* ovf = t2h_split_overflow_flag_ptr();
