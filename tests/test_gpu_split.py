@@ -30,7 +30,7 @@ def test_split_rows_carry_22_bits_and_match_the_host_pack():
     assert ((back - x).abs() <= x.abs() * 2.0**-21 + 2.0**-36).all()
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize('M,N,K', [(4096, 512, 512), (1024, 1536, 512), (512, 512, 2048), (130, 96, 64),
                                    (40, 32, 32)])
 def test_gemm_split(cfg, M, N, K):
@@ -223,7 +223,10 @@ def test_folded_layernorm_producer_and_consumer(M):
     x_plain = torch.empty(M, C, device=DEV)
     ops.gemm_split(ops.split_rows(y.to(DEV)), ops.pack_split_rows_host(wp).to(DEV), M, C, C, out=x_plain,
                    bias=bp.to(DEV), residual=res.to(DEV))
-    assert torch.equal(x, x_plain)                                    # the extra outputs change nothing
+    if M > 64:
+        assert torch.equal(x, x_plain)                                # the extra outputs change nothing
+    else:                                                             # (few rows: the plain call takes the few-rows kernel)
+        assert (x - x_plain).abs().max().item() < 1e-5
     assert torch.equal(xs.view(-1), ops.split_rows(x).view(-1))       # split(x), bitwise
     xc = x.cpu().double().view(M, C // 32, 32)
     mu = xc.mean(-1)

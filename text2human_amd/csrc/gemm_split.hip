@@ -823,6 +823,53 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #endif
 }
 
+// ---- a handful of rows (the last layer's tail on the changed rows of a sampling step, M ~ 16):
+// the tiled kernel gives such a problem N / 64 workgroups that walk K alone (fc2: 8 workgroups x 64
+// K steps, 20 us).  Here a workgroup owns a 16 x 16 output tile, its 8 waves split K between them
+// (tiles w, w + 8, ..) and feed v_mfma_f32_16x16x32_f16 STRAIGHT from global memory -- a lane's
+// fragment of a split row is one 16-byte piece -- and the partial sums meet in LDS, in wave order.
+constexpr int SKINNY_WAVES = 8;
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_split_skinny_kernel(const t2h_gemm_split_args p, int* const ovf) {
+  __shared__ __attribute__((aligned(16))) float red[SKINNY_WAVES][16 * 16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 15, kg = lane >> 4;  // A row / B row (= output column) and 8-wide k group of the lane
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int nk = p.K / 32;
+  const int64_t row_b = (int64_t)nk * SP_TILE_B;
+  const char* ap = reinterpret_cast<const char*>(p.A) + (int64_t)min(m0 + r, p.M - 1) * row_b + kg * 16;
+  const char* bp = reinterpret_cast<const char*>(p.B) + (int64_t)min(n0 + r, p.N - 1) * row_b + kg * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_lo = acc;
+#pragma unroll 4
+  for (int t = wave; t < nk; t += SKINNY_WAVES) {
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(ap + (int64_t)t * SP_TILE_B);
+    const f16x8 al = *reinterpret_cast<const f16x8*>(ap + (int64_t)t * SP_TILE_B + 64);
+    const f16x8 bh = *reinterpret_cast<const f16x8*>(bp + (int64_t)t * SP_TILE_B);
+    const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + (int64_t)t * SP_TILE_B + 64);
+    acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_lo, 0, 0, 0);
+    acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_lo, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+  }
+  // accumulator register e of lane l: row 4 (l >> 4) + e, column l & 15
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][(4 * kg + e) * 16 + r] = fmaf(acc_lo[e], T2H_SPLIT_LO_INV, acc[e]);
+  __syncthreads();
+  if (wave != 0) return;
+  const int rl = lane >> 2, c4 = (lane & 3) * 4;
+  const int row = m0 + rl, col = n0 + c4;
+  if (row >= p.M || col >= p.N) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][rl * 16 + c4]);
+#pragma unroll
+  for (int w = 1; w < SKINNY_WAVES; ++w) v += *reinterpret_cast<const f32x4*>(&red[w][rl * 16 + c4]);
+  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+  if (p.epi_act == 1) v = gelu_erf_v(v);
+  else if (p.epi_act == 2)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
+  if (p.C) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
+  if (p.C_split) t2h_store_split4(p.C_split, row, p.N, col, v, ovf);
+}
+
 // fp32 [rows, C] (ld) -> split rows; one thread per 4 consecutive columns
 __global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ out, int64_t total,
                                   int C, int* ovf) {
@@ -916,6 +963,17 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     else if (tiles128 >= 1024) cfg = 1;
     else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
     else cfg = 0;
+  }
+  const bool skinny_ok = a.N % 16 == 0 && !a.Vt && !a.ln_part_out && !a.ln_part_in &&
+                         (a.bias == nullptr || t2h_aligned16(a.bias));
+  if (g_force_split_cfg < 0 && a.M <= 64 && skinny_ok) cfg = 9;
+  if (cfg == 9) {
+    T2H_REQUIRE(skinny_ok, "t2h_gemm_split_f32: the few-rows kernel needs N %% 16 == 0 and no Vt / LayerNorm routing");
+    int* ovf = t2h_split_overflow_flag_ptr();
+    T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
+    hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), 0, s, a, ovf);
+    T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
+    return T2H_OK;
   }
   switch (cfg) {
     case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64
