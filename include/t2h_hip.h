@@ -160,7 +160,7 @@ int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
  * Synchronises `stream`, returns 1 if the flag was raised since the last reset, 0 if not, < 0 on
  * error; reset != 0 clears it.  The host side checks it once per sampling run and raises. */
 int t2h_split_overflow(int32_t reset, void* stream);
-int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..8, 9 = the few-rows kernel, -1 auto */
+int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..6, 8 (ping-pong LDS-DMA), 9 (few-rows kernel), -1 auto */
 /* fp32 [rows, C] (row stride ldx) -> split rows */
 int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);
 /* producers that emit split rows directly: LayerNorm (transformer_arch.py:93-95)

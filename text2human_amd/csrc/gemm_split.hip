@@ -140,13 +140,14 @@ __device__ long long* g1_timing = nullptr;  // debug builds only (tools/gemm_pha
 // the result is deterministic.  It gives a tile that only fills the chip at one block
 // per CU (N = 512 at M = 4096) two waves per SIMD without shrinking the wave tile.
 //
-// PP = 1 ("ping-pong", 8 waves, KS = 1): the two waves that share a SIMD (w and w + 4) run the
-// SAME loop one phase apart -- [read the K tile's fragments from LDS] barrier [its matrix
-// instructions, with the staging stores of a later tile behind them] barrier -- so each SIMD's
-// matrix pipe always has one wave in its matrix phase while the partner's LDS reads are in
-// flight.  In the plain loop all eight waves leave the barrier together, read together and wait
-// for the same fragments: its 256x128 main loop took 1.3 us per K step against 0.77 us of matrix
-// instructions.
+// PP = 2 ("ping-pong", 8 waves, KS = 1): the two waves that share a SIMD (w and w + 4) run the
+// SAME loop one phase apart -- [read the K tile's fragments from LDS, request a later tile by
+// LDS-DMA] barrier [its matrix instructions] barrier -- so each SIMD's matrix pipe always has one
+// wave in its matrix phase while the partner's LDS reads are in flight.  In the plain loop all
+// eight waves leave the barrier together, read together and wait for the same fragments: its
+// 256x128 main loop took 1.3 us per K step against 0.77 us of matrix instructions.  (The same
+// schedule with register staging, PP = 1 of round 2, gained nothing and was removed:
+// profiles/r02_gemm_pingpong_ablation_v*.log.)
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int PP>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p, int* const ovf) {
   constexpr int NT = 64 * WARPS_M * WARPS_N;  // threads per K group
@@ -263,8 +264,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     // staging registers, no ds_write pass).  A DMA instruction fills 1 KiB = 8 rows x 128 B
     // lane-linearly, so the image is unpadded; the 16-byte fragment reads stay conflict free through
     // an XOR swizzle applied on the DMA's SOURCE address and on the read address: logical piece c of
-    // row r lives at piece c ^ ((r >> 1) & 7).  Three tile buffers; phases as in PP = 1 (group 1 one
-    // phase late).  A wave reading tile j requests its 8-row groups of tile j + 2 into the buffer tile
+    // row r lives at piece c ^ ((r >> 1) & 7).  Three tile buffers; group 1 runs one phase late
+    // (phase 2t: group 0 reads tile t; 2t + 1: group 0 computes it, group 1 reads it; 2t + 2: group 1
+    // computes it).  A wave reading tile j requests its 8-row groups of tile j + 2 into the buffer tile
     // j - 1 left (last read two / one phases ago).  Its pieces of tile j + 1 must have landed before
     // the barrier in front of phase 2j + 2: group 0 checks at the end of its matrix phase (1.5 steps
     // after the request), group 1 at the end of its read phase (1 step).
@@ -403,117 +405,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     if (grp == 0) pp_barrier();  // group 1's last matrix phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead requests too, before
     __syncthreads();                                  // the tile buffers are reused by the epilogue
-  } else if constexpr (PP == 1) {
-    static_assert(KS == 1 && NWG == 8, "ping-pong: 8 waves, no K split");
-    static_assert(PIECES % NT == 0, "ping-pong: whole pieces per thread");
-    // waves w and w + 4 share a SIMD; group 1 runs one phase late
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-    // (the fences keep the compiler from moving matrix instructions or LDS reads into the partner's phase)
-    auto pp_barrier = [] {
-      __builtin_amdgcn_sched_barrier(0);
-#ifndef T2H_SDBG_NOBAR
-      __syncthreads();
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    static_assert((BM * SP_PIECES) % NT == 0, "each round of pieces belongs to one operand");
-    constexpr int LA = BM * SP_PIECES / NT;
-    unsigned src[L];
-    int dst[L];
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-      const int q = tid + NT * i;
-      const int row = q / SP_PIECES, pc = q - row * SP_PIECES;
-      const bool isA = i < LA;
-      const int grow = isA ? min(LM0 + row, p.M - 1) : min(LN0 + row - BM, p.N - 1);
-      src[i] = (unsigned)grow * (unsigned)row_b + pc * 16;
-      dst[i] = row * SP_LDS_ROW + pc * 16;
-    }
-    const char* const gA = reinterpret_cast<const char*>(p.A);
-    const char* const gB = reinterpret_cast<const char*>(p.B);
-    u32x4 rg[L];  // ONE register set: a piece is re-requested right after it went to LDS
-    // piece q of the staged tile -> LDS buffer `buf`, then request it for K tile `kt_next`.  The L
-    // requests of a tile are issued oldest first, so L - 1 younger ones are outstanding whenever
-    // piece q is waited for.
-    auto restage = [&](int q, int buf, int kt_next) {
-      __builtin_amdgcn_sched_barrier(0);
-      wait_vmcnt16<L - 1>(rg[q]);
-#ifdef T2H_SDBG_NOPUT
-      asm volatile("" ::"v"(rg[q]), "v"(dst[q] + buf));
-#else
-      *reinterpret_cast<u32x4*>(smem + buf * BUF_B + dst[q]) = rg[q];
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      gload16_async(rg[q], src[q], (q < LA ? gA : gB) + (int64_t)min(kt_next, last) * K_STEP_B);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // Who writes what when.  Phase 2t: group 0 reads tile t's fragments; 2t + 1: group 0 computes
-    // tile t and group 1 reads it; 2t + 2: group 1 computes it.  Tile t + 2 shares tile t's buffer, may
-    // be written from phase 2t + 2 on and must be complete by the end of phase 2t + 3: exactly the two
-    // phases in which the groups read tile t + 1.  So the staging stores go into the READ phase (a wave
-    // reading tile j stores its pieces of tile j + 1 and requests tile j + 2) and the matrix phase is
-    // nothing but matrix instructions: a ds_write_b128 between them held the issuing wave for the
-    // store path's 13 cycles times however many waves stored at once, and the matrix pipe with it
-    // (removing the stores took the 16-step loop from 21 to 14.4 us; all data movement, to 13.1).
-#pragma unroll
-    for (int i = 0; i < L; ++i) gload16_async(rg[i], src[i], i < LA ? gA : gB);
-    ln_prologue();
-#pragma unroll
-    for (int q = 0; q < L; ++q) restage(q, 0, 1);
-    pp_barrier();
-    G1_MARK(1);
-    if (grp == 1) pp_barrier();  // phase 0 belongs to group 0
-    constexpr int PA[3] = {1, 0, 0};
-    constexpr int PB[3] = {0, 1, 0};
-    constexpr int PC[3] = {1, 1, 0};
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* Ab = smem + (kt & 1) * BUF_B + (wm0 + l31) * SP_LDS_ROW + hh * 16;
-      const char* Bb = smem + (kt & 1) * BUF_B + (BM + wn0 + l31) * SP_LDS_ROW + hh * 16;
-      f16x8 af[2][TM][2], bfr[2][TN][2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-#ifdef T2H_SDBG_NOFRAG
-            asm volatile("" : "=v"(af[u][ti][pl]) : "v"(Ab));
-#else
-            af[u][ti][pl] = *reinterpret_cast<const f16x8*>(Ab + ti * 32 * SP_LDS_ROW + pl * 64 + u * 32);
-#endif
-#pragma unroll
-        for (int tj = 0; tj < TN; ++tj)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-#ifdef T2H_SDBG_NOFRAG
-            asm volatile("" : "=v"(bfr[u][tj][pl]) : "v"(Bb));
-#else
-            bfr[u][tj][pl] = *reinterpret_cast<const f16x8*>(Bb + tj * 32 * SP_LDS_ROW + pl * 64 + u * 32);
-#endif
-      }
-#pragma unroll
-      for (int q = 0; q < L; ++q) restage(q, (kt + 1) & 1, kt + 2);
-      pp_barrier();
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int ti = 0; ti < TM; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < TN; ++tj) {
-#ifdef T2H_SDBG_NOMMA
-              asm volatile("" : "+v"(acc[PC[t]][ti][tj]) : "v"(af[u][ti][PA[t]]), "v"(bfr[u][tj][PB[t]]));
-#else
-              acc[PC[t]][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][ti][PA[t]], bfr[u][tj][PB[t]],
-                                                                           acc[PC[t]][ti][tj], 0, 0, 0);
-#endif
-            }
-      pp_barrier();
-    }
-    if (grp == 0) pp_barrier();  // group 1's last matrix phase
-#pragma unroll
-    for (int i = 0; i < L; ++i) wait_vmcnt16<0>(rg[i]);
   } else {  // (scope: the staging registers and addresses are dead before the epilogue -- without it the
      // register allocator of ROCm 7.2 spilled 423 registers in the 256x128 instantiation)
   // ---- per-thread staging slots (fixed for the whole kernel).  Rows beyond M / N are
@@ -982,8 +873,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     case 4: return launch_split<256, 128, 4, 2>(a, s);  // 8 waves, wave tile 64x64
     case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
     case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
-    case 7: return launch_split<256, 128, 4, 2, 1, 1>(a, s);  // 8 waves, wave tile 64x64, ping-pong
-    case 8: return launch_split<256, 128, 4, 2, 1, 2>(a, s);  // the same with LDS-DMA staging
+    case 8: return launch_split<256, 128, 4, 2, 1, 2>(a, s);  // 8 waves, wave tile 64x64, ping-pong LDS-DMA loop
     default: return launch_split<128, 64, 2, 2>(a, s);  // 4 waves, wave tile 64x32
   }
 }
