@@ -277,7 +277,8 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   float* const smem = reinterpret_cast<float*>(smem_raw);
   int* const bar = reinterpret_cast<int*>(smem_raw + SMEM_B);  // one counter per key half
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform values in scalar registers
   const long long tm0 = TM_NOW();
   long long tm_stage = 0, tm_comp = 0;
   if (tid < 2) bar[tid] = 0;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   // staging per key half (256 threads): K tile = 64 keys x 16 pieces (thread: key s_t/4,
   // pieces (s_t&3) + 4i), Vt tile = 128 (plane, d) rows x 8 pieces (thread: row s_t/8 + 32i,
   // piece s_t&7): 4 + 4 16-byte pieces per thread, addresses affine in i
-  const int s_half = tid >> 8, s_t = tid & 255;
+  const int s_half = wave >> 2, s_t = tid & 255;
   const int half_keys = T / 2;
   char* const Ks_st = smem_raw + s_half * SKV_TILE;
   char* const Vs_st = Ks_st + SK_TILE;
@@ -405,18 +406,25 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
     // ---- online softmax over the tile's 64 keys: this lane's 2 x 16 + the partner half's.  ONE
     // rescale of the running state per tile, skipped (wave-uniformly) when no lane's maximum moved:
     // alpha would be exp(0) = 1 exactly, so skipping changes no bit.
+    // Softmax in the base-2 domain: p = exp2(s c - M) with c = log2(e) / sqrt(d) and M the running
+    // maximum of s c (one fma + v_exp_f32 per score; the compensated exp of the exact-fp32 kernel costs
+    // six more instructions per score, and the vector ALU, not the matrix pipe, is what this loop waits
+    // for).  M is the SAME rounded number in every term of a row -- the rescale factor below is formed
+    // from the rounded values too -- so its rounding cancels in the normalisation; what remains is the
+    // rounding of the argument, |arg| ulp on a term of weight 2^arg: below the fp32 summation error.
+    constexpr float SC = 0.125f * 1.44269504088896340736f;
     float mx = -INFINITY;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        st[ks][r] = fmaf(st_lo[ks][r], T2H_SPLIT_LO_INV, st[ks][r]) * 0.125f;
+        st[ks][r] = fmaf(st_lo[ks][r], T2H_SPLIT_LO_INV, st[ks][r]);
         mx = fmaxf(mx, st[ks][r]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * SC;
     const float m_new = fmaxf(m_run, mx);
     if (__any(m_new > m_run)) {
-      const float alpha = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);  // first tile: 0
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 0
       l_run *= alpha;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -436,9 +444,9 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
 #ifdef T2H_MDBG_NOEXP
-        st[ks][r] = st[ks][r] - m_run;
+        st[ks][r] = fmaf(st[ks][r], SC, -m_run);
 #else
-        st[ks][r] = fast_exp(st[ks][r] - m_run);
+        st[ks][r] = __builtin_amdgcn_exp2f(fmaf(st[ks][r], SC, -m_run));
 #endif
         psum += st[ks][r];
       }
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   if (kh == 0) {
     const float m2 = Mx[qw * 64 + lane], l2 = Lx[qw * 64 + lane];
     const float m = fmaxf(m_run, m2);
-    const float a1 = expf(m_run - m), a2 = expf(m2 - m);
+    const float a1 = exp2f(m_run - m), a2 = exp2f(m2 - m);  // (maxima are kept in the base-2 domain)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
