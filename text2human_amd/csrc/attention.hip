@@ -270,8 +270,9 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
                                                         const uint16_t* __restrict__ vt, float* __restrict__ y,
                                                         uint16_t* __restrict__ y_split, int T, int C, int n_head,
                                                         int* ovf) {
-  // two (K, Vt) tile pairs; reused at the end for the merge + output transpose staging
-  constexpr int SMEM_B = 2 * SKV_TILE > (4 * 32 * 64 + 4 * 32 * O_LD) * 4 ? 2 * SKV_TILE
+  // two (K, Vt) tile pairs per key half (double buffer); reused at the end for the merge + output
+  // transpose staging
+  constexpr int SMEM_B = 4 * SKV_TILE > (4 * 32 * 64 + 4 * 32 * O_LD) * 4 ? 4 * SKV_TILE
                                                                            : (4 * 32 * 64 + 4 * 32 * O_LD) * 4;
   __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_B + 16];
   float* const smem = reinterpret_cast<float*>(smem_raw);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   // piece s_t&7): 4 + 4 16-byte pieces per thread, addresses affine in i
   const int s_half = wave >> 2, s_t = tid & 255;
   const int half_keys = T / 2;
-  char* const Ks_st = smem_raw + s_half * SKV_TILE;
+  char* const Ks_st = smem_raw + s_half * (2 * SKV_TILE);  // + buf * SKV_TILE
   char* const Vs_st = Ks_st + SK_TILE;
   const char* const vt_b = reinterpret_cast<const char*>(vt) + ((int64_t)(b * n_head + head) * 2 * HD) * T * 2;
   const char* const ksrc = qk_b + (int64_t)(s_half * half_keys + (s_t >> 2)) * row_b +
@@ -340,11 +341,11 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
       vreg[i] = *reinterpret_cast<const u32x4*>(vsrc + it * KT * 2 + i * v_step);
     }
   };
-  auto store_kv = [&]() {
+  auto store_kv = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(Ks_st + kdst + i * 64) = kreg[i];
-      *reinterpret_cast<u32x4*>(Vs_st + vdst + i * 32 * SV_ROW) = vreg[i];
+      *reinterpret_cast<u32x4*>(Ks_st + buf * SKV_TILE + kdst + i * 64) = kreg[i];
+      *reinterpret_cast<u32x4*>(Vs_st + buf * SKV_TILE + vdst + i * 32 * SV_ROW) = vreg[i];
     }
   };
 
@@ -352,8 +353,7 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   constexpr int PA[3] = {1, 0, 0};
   constexpr int PB[3] = {0, 1, 0};
 
-  const char* const Ks = smem_raw + kh * SKV_TILE;
-  const char* const Vs = Ks + SK_TILE;
+  const char* const Ks0 = smem_raw + kh * (2 * SKV_TILE);
   const int nit = half_keys / KT;
   load_kv(0);
   // staging threads [0,256) are waves 0-3 = key half 0, [256,512) waves 4-7 = half 1, so a
@@ -362,17 +362,22 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
   const long long tm1 = TM_NOW();
   // the second-dispatched half of the workgroup loses every issue arbitration against its older SIMD
   // partner (measured: its loop took 37k cycles against 26k): static priority evens the two out
+#ifndef T2H_MHA_NOPRIO
   if (kh == 1) __builtin_amdgcn_s_setprio(1);
-  for (int it = 0; it < nit; ++it) {
-    const long long ta = TM_NOW();
-#ifndef T2H_MDBG_NOSTAGE
-    half_barrier(bar + kh, bar_n += 4, lane);  // previous tile fully consumed by this half
-    store_kv();
-    half_barrier(bar + kh, bar_n += 4, lane);
-    if (it + 1 < nit) load_kv(it + 1);
 #endif
+  // Double-buffered tiles, ONE barrier per tile: tile it + 1 goes from its staging registers into
+  // the other buffer after tile it's softmax (that buffer was released by the barrier that ended
+  // tile it - 1), tile it + 2 is requested right behind, and the barrier at the end of the iteration
+  // publishes tile it + 1.
+#ifndef T2H_MDBG_NOSTAGE
+  store_kv(0);
+  if (nit > 1) load_kv(1);
+  half_barrier(bar + kh, bar_n += 4, lane);
+#endif
+  for (int it = 0; it < nit; ++it) {
     const long long tb = TM_NOW();
-    tm_stage += tb - ta;
+    const char* const Ks = Ks0 + (it & 1) * SKV_TILE;
+    const char* const Vs = Ks + SK_TILE;
 
     // ---- S^T = K Q^T for BOTH 32-key sub-tiles of the tile.  Issue order (l,h)0 (l,h)1 (h,h)0
     // (h,l)0 (h,l)1 (h,h)1 per k16-step: consecutive matrix instructions never share an
@@ -435,6 +440,12 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
         }
       m_run = m_new;
     }
+#ifndef T2H_MDBG_NOSTAGE
+    if (it + 1 < nit) {
+      store_kv((it + 1) & 1);
+      if (it + 2 < nit) load_kv(it + 2);
+    }
+#endif
     float psum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -482,7 +493,12 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
     }
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
-    tm_comp += TM_NOW() - tb;
+    const long long tc = TM_NOW();
+    tm_comp += tc - tb;
+#ifndef T2H_MDBG_NOSTAGE
+    if (it + 1 < nit) half_barrier(bar + kh, bar_n += 4, lane);  // tile it + 1 published, tile it released
+#endif
+    tm_stage += TM_NOW() - tc;
   }
 
 #pragma unroll

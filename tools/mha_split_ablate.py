@@ -14,7 +14,8 @@ VARIANTS = (('full', []), ('full+timing', ['-DT2H_MHA_TIMING']), ('noexp', ['-DT
             ('nostage', ['-DT2H_MDBG_NOSTAGE']),
             ('mma only', ['-DT2H_MDBG_NOEXP', '-DT2H_MDBG_NOSPLIT', '-DT2H_MDBG_NOSTAGE']))
 if len(sys.argv) > 1 and sys.argv[1] == 'flags':
-    VARIANTS = (('full', []), ('no SLP vectorizer', ['-fno-slp-vectorize']), ('full', []), ('no SLP vectorizer', ['-fno-slp-vectorize']))
+    VARIANTS = (('full', []), ('no SLP vectorizer', ['-fno-slp-vectorize']), ('no setprio', ['-DT2H_MHA_NOPRIO']),
+                ('no setprio+timing', ['-DT2H_MHA_NOPRIO', '-DT2H_MHA_TIMING']), ('full', []), ('no setprio', ['-DT2H_MHA_NOPRIO']))
 if len(sys.argv) > 1 and sys.argv[1] == 'timing':
     VARIANTS = (('full', []), ('full+timing', ['-DT2H_MHA_TIMING']), ('nomma', ['-DT2H_MDBG_NOMMA']), ('mma only', ['-DT2H_MDBG_NOEXP', '-DT2H_MDBG_NOSPLIT', '-DT2H_MDBG_NOSTAGE']))
 B, T, H, C = 8, 512, 8, 512
