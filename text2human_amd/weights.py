@@ -5,7 +5,10 @@ keys and parameter names of models/sample_model.py:124-181,397-410) and
 validates them the way `load_state_dict(strict=True)` would: a missing /
 unexpected key or a shape mismatch raises RuntimeError.
 
-Repacks (all fp32, device resident, done once at model construction):
+Repacks (device resident, done once at model construction; fp32, plus the two-fp16-plane "split
+row" copies of the sampler Linears and of the decoders' convolutions that the split-precision
+kernels multiply -- `pack_transformer`, `add_split_conv_weights`; the LayerNorm-folded copies only
+with T2H_FOLD_LN=1):
   * 3x3 conv  [Cout,Cin,3,3] -> [Cout, 9*Cin']  K order [tap(dy,dx)][cin],
     Cin' = Cin rounded up to a multiple of 32 (zero columns);
   * 1x1 conv  [Cout,Cin,1,1] -> [Cout, Cin];
