@@ -3,7 +3,7 @@ split-row + Vt outputs, proj with the residual, fc1 with the GELU split-row epil
 residual) timed per tile configuration of t2h_gemm_split_f32: interleaved rounds in one process,
 median per call, plus the back-to-back chain of all four.  GPU only.
 
-    python tools/sampler_gemm_bench.py [batch=8] [cfgs=-1,0,4,6] [rounds=7]
+    python tools/sampler_gemm_bench.py [batch=8] [cfgs=-1,0,4,6,8] [rounds=7]
 """
 import os
 import statistics
@@ -46,11 +46,9 @@ def main():
 
     def usable(cfg, name):
         k = 4 * C if name == 'fc2' else C
-        if cfg == 9:
-            return name != 'qkv' and k % 64 == 0
-        if cfg == 10:
-            return name != 'qkv' and k % 128 == 0
-        if cfg == 5:
+        if cfg == 6:
+            return k % 64 == 0
+        if cfg in (5, 9):   # 256-column tiles do not divide the value-head boundary; 9 = few-rows kernel (no Vt)
             return name != 'qkv'
         return True
 
