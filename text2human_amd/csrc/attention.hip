@@ -544,10 +544,11 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
       }
   }
   __syncthreads();
-  if (kh == 0) {
+  {  // both key halves store: 16 of the 32 staged rows each
     const int64_t grow = (int64_t)b * T + q0;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it2 = 0; it2 < 2; ++it2) {
+      const int it = it2 + 2 * kh;
       const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
       const f32x4 va = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8);
       const f32x4 vb = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8 + 4);
