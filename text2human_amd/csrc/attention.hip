@@ -21,7 +21,15 @@
 // key pair {(s&3)+8(s>>2)+4h, h=0,1}.  So P never leaves registers, the online
 // softmax statistics (running max m, running sum l) are per-lane scalars, and
 // rescaling the O^T accumulator is a plain per-lane multiply.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
+
+#ifndef T2H_MHA_PIPE_DEFAULT
+#define T2H_MHA_PIPE_DEFAULT 1
+#endif
 
 namespace {
 
@@ -568,6 +576,297 @@ __global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restri
 #endif
 }
 
+// the software-pipelined variant (mha_split_pipe_kernel) stages its tiles by LDS-DMA: unpadded images
+constexpr int DK_TILE = KT * 256;            // K tile: 64 keys x 256 B
+constexpr int DV_TILE = 2 * HD * 128;        // Vt tile: 128 (plane, d) rows x 64 keys x 2 B
+constexpr int DKV_TILE = DK_TILE + DV_TILE;  // per key half and buffer
+
+__global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __restrict__ qk, int ld_cols,
+                                                        const uint16_t* __restrict__ vt, float* __restrict__ y,
+                                                        uint16_t* __restrict__ y_split, int T, int C, int n_head,
+                                                        int* ovf) {
+  // two (K, Vt) tile pairs per key half (double buffer); reused at the end for the merge + output
+  // transpose staging
+  constexpr int SMEM_B = 4 * DKV_TILE > (4 * 32 * 64 + 4 * 32 * O_LD) * 4 ? 4 * DKV_TILE
+                                                                           : (4 * 32 * 64 + 4 * 32 * O_LD) * 4;
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_B + 16];
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  int* const bar = reinterpret_cast<int*>(smem_raw + SMEM_B);  // one counter per key half
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform values in scalar registers
+  const long long tm0 = TM_NOW();
+  long long tm_stage = 0, tm_comp = 0;
+  if (tid < 2) bar[tid] = 0;
+  __syncthreads();
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int qw = wave & 3, kh = wave >> 2;
+  int qt, head, b;
+  {
+    const int nqt = T / QB, total = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    qt = lin % nqt;
+    const int hb = lin / nqt;
+    head = hb % n_head;
+    b = hb / n_head;
+  }
+  const int q0 = qt * QB + qw * 32;
+  const int64_t row_b = (int64_t)(ld_cols / 32) * T2H_SPLIT_TILE_B;  // bytes per split row
+  const char* const qk_b = reinterpret_cast<const char*>(qk) + (int64_t)b * T * row_b;
+  const int q_tile0 = 2 * head, k_tile0 = C / 32 + 2 * head;  // 32-column tiles of this head's q / k
+
+  // Q fragments: k16-step kk covers d = 16 kk + 8 h .. + 7 of plane pl
+  f16x8 qf[4][2];
+  {
+    const char* qp = qk_b + (int64_t)(q0 + l31) * row_b + q_tile0 * T2H_SPLIT_TILE_B + hh * 16;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        qf[kk][pl] = *reinterpret_cast<const f16x8*>(qp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
+  }
+
+  f32x16 o_acc[2], o_lo[2];  // O^T = o_acc + 2^-11 o_lo (hi*hi and the cross products)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[dt][r] = o_lo[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // ---- staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  Tile
+  // images are unpadded -- K: 64 keys x 256 B, Vt: 128 (plane, d) rows x 128 B -- and the 16-byte
+  // fragment reads stay conflict free through an XOR swizzle applied on the DMA's SOURCE piece and on
+  // the read address: K piece p of key r lives at p ^ (r & 15), Vt piece p of row r at p ^ ((r >> 1) & 7).
+  // A DMA instruction fills 1 KiB lane-linearly = 4 K rows or 8 Vt rows; wave w of the half issues
+  // chunks 4w .. 4w + 3 of either tile (rows 16w + 4i + (lane >> 4) / 32w + 8i + (lane >> 3)).
+  const int half_keys = T / 2;
+  const int w4 = wave & 3;
+  const char* const vt_b = reinterpret_cast<const char*>(vt) + ((int64_t)(b * n_head + head) * 2 * HD) * T * 2;
+  const unsigned lds_half = (unsigned)(uintptr_t)smem_raw + kh * (2 * DKV_TILE);  // this half's two buffers
+  const char* const kbase = qk_b + (int64_t)(kh * half_keys) * row_b + k_tile0 * T2H_SPLIT_TILE_B;
+  const char* const vbase = vt_b + (int64_t)(kh * half_keys) * 2;
+  const unsigned k_rowoff = (unsigned)(16 * w4 + (lane >> 4)) * (unsigned)row_b;
+  const unsigned k_b16 = (unsigned)((lane & 15) ^ (lane >> 4)) * 16;  // source piece of chunk i: this ^ 64 i
+  const unsigned v_rowoff = (unsigned)(32 * w4 + (lane >> 3)) * (unsigned)(T * 2);
+  const unsigned v_b16 = (unsigned)((lane & 7) ^ (lane >> 4)) * 16;   // source piece of chunk i: this ^ 64 (i & 1)
+  auto dma16 = [&](unsigned voff, const char* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+  };
+  auto dma_k = [&](int it, int buf) {
+    const char* const sb = kbase + (int64_t)it * KT * row_b;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_half + buf * DKV_TILE + 4 * w4 * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(k_rowoff + (unsigned)(4 * i) * (unsigned)row_b + (k_b16 ^ (64u * i)), sb, dst + i * 1024);
+  };
+  auto dma_v = [&](int it, int buf) {
+    const char* const sb = vbase + it * KT * 2;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_half + buf * DKV_TILE + DK_TILE + 4 * w4 * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(v_rowoff + (unsigned)(8 * i) * (unsigned)(T * 2) + (v_b16 ^ (64u * (i & 1))), sb, dst + i * 1024);
+  };
+  auto dma_landed = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  const char* const Ks0 = smem_raw + kh * (2 * DKV_TILE);
+  const int nit = half_keys / KT;
+  // fragment addresses in the swizzled images
+  const unsigned xk16 = (unsigned)(hh ^ (l31 & 15)) * 16, xv16 = (unsigned)(hh ^ ((l31 >> 1) & 7)) * 16;
+  // S^T = K Q^T for BOTH 32-key sub-tiles of the tile at `Ks`.  Issue order (l,h)0 (l,h)1 (h,h)0
+  // (h,l)0 (h,l)1 (h,h)1 per k16-step: consecutive matrix instructions never share an accumulator.
+  auto s_tile = [&](const char* Ks, f32x16 (&st)[2], f32x16 (&st_lo)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[ks][r] = st_lo[ks][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f16x8 kf[2][2];  // [sub-tile][plane]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          kf[ks][pl] = *reinterpret_cast<const f16x8*>(
+              Ks + (ks * 32 + l31) * 256 + ((unsigned)(((kk >> 1) * 8 + pl * 4 + (kk & 1) * 2) * 16) ^ xk16));
+      st_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][1], qf[kk][0], st_lo[0], 0, 0, 0);
+      st_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][1], qf[kk][0], st_lo[1], 0, 0, 0);
+      st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[kk][0], st[0], 0, 0, 0);
+      st_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[kk][1], st_lo[0], 0, 0, 0);
+      st_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][0], qf[kk][1], st_lo[1], 0, 0, 0);
+      st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][0], qf[kk][0], st[1], 0, 0, 0);
+    }
+  };
+
+  int bar_n = 0;
+  const long long tm1 = TM_NOW();
+  if (kh == 1) __builtin_amdgcn_s_setprio(1);  // see mha_split_kernel
+  // ---- software pipeline over the key tiles (two (K, Vt) buffers per half, one barrier per tile):
+  // the matrix pipe forms S^T of tile j + 1 while the vector ALU does the softmax of tile j -- the two
+  // are independent, so the compiler interleaves them instead of the wave waiting for its own matrix
+  // results.  Iteration j requests K(j+2) into the buffer whose K(j) was last read by S^T(j), in
+  // iteration j-1, and V(j+1) into the buffer whose V(j-1) was last read in iteration j-1.
+  constexpr float SC = 0.125f * 1.44269504088896340736f;  // log2(e) / sqrt(d)
+  f32x16 sc[2];  // S^T of the current tile (folded, unscaled); becomes the probabilities in place
+  {
+    f32x16 st[2], st_lo[2];
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (nit > 1) dma_k(1, 1);
+    dma_landed();
+    half_barrier(bar + kh, bar_n += 4, lane);
+    s_tile(Ks0, st, st_lo);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[ks][r] = fmaf(st_lo[ks][r], T2H_SPLIT_LO_INV, st[ks][r]);
+    half_barrier(bar + kh, bar_n += 4, lane);  // K(0) consumed by every wave before K(2) replaces it
+  }
+  auto iteration = [&](int it, auto next_c) {
+    constexpr bool NEXT = decltype(next_c)::value;  // also form S^T of tile it + 1 (all but the last)
+    const long long tb = TM_NOW();
+    const int buf = it & 1;
+    const char* const Vs = Ks0 + buf * DKV_TILE + DK_TILE;
+    if (it + 2 < nit) dma_k(it + 2, buf);
+    if (it + 1 < nit) dma_v(it + 1, buf ^ 1);
+    // softmax in the base-2 domain (see mha_split_kernel): p = exp2(s c - M)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[ks][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * SC;
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 0
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          o_acc[dt][r] *= alpha;
+          o_lo[dt][r] *= alpha;
+        }
+      m_run = m_new;
+    }
+    f32x16 sn[2], sn_lo[2];
+    if constexpr (NEXT) s_tile(Ks0 + (buf ^ 1) * DKV_TILE, sn, sn_lo);
+    float psum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sc[ks][r] = __builtin_amdgcn_exp2f(fmaf(sc[ks][r], SC, -m_run));
+        psum += sc[ks][r];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f16x8 pf[2];
+        if (j == 0) split8<0>(sc[ks], pf[0], pf[1]);
+        else split8<1>(sc[ks], pf[0], pf[1]);
+        f16x8 vf[2][2];  // [d half][plane]
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            vf[dt][pl] = *reinterpret_cast<const f16x8*>(Vs + (pl * HD + dt * 32 + l31) * 128 +
+                                                          ((unsigned)((ks * 4 + j * 2) * 16) ^ xv16));
+        o_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], pf[0], o_lo[0], 0, 0, 0);
+        o_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], pf[0], o_lo[1], 0, 0, 0);
+        o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pf[0], o_acc[0], 0, 0, 0);
+        o_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pf[1], o_lo[0], 0, 0, 0);
+        o_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[1], o_lo[1], 0, 0, 0);
+        o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[0], o_acc[1], 0, 0, 0);
+      }
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run += psum;
+    if constexpr (NEXT) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[ks][r] = fmaf(sn_lo[ks][r], T2H_SPLIT_LO_INV, sn[ks][r]);
+    }
+    const long long tc = TM_NOW();
+    tm_comp += tc - tb;
+    if constexpr (NEXT) {
+      dma_landed();
+      half_barrier(bar + kh, bar_n += 4, lane);  // tile it + 1 published, tile it released
+    }
+    tm_stage += TM_NOW() - tc;
+  };
+  for (int it = 0; it + 1 < nit; ++it) iteration(it, std::true_type{});
+  iteration(nit - 1, std::false_type{});
+
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[dt][r] = fmaf(o_lo[dt][r], T2H_SPLIT_LO_INV, o_acc[dt][r]);
+  // ---- merge the two key halves: waves 4-7 publish (m, l, O), waves 0-3 combine
+  const long long tm2 = TM_NOW();
+  __syncthreads();
+  float* const Ox = smem;                // [4 waves][32 regs][64 lanes]
+  float* const Mx = smem + 4 * 32 * 64;  // borrowed from the staging area below:
+  float* const Lx = Mx + 4 * 64;         // consumed before that area is written
+  if (kh == 1) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ox[(qw * 32 + dt * 16 + r) * 64 + lane] = o_acc[dt][r];
+    Mx[qw * 64 + lane] = m_run;
+    Lx[qw * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  float inv_l = 0.f;
+  if (kh == 0) {
+    const float m2 = Mx[qw * 64 + lane], l2 = Lx[qw * 64 + lane];
+    const float m = fmaxf(m_run, m2);
+    const float a1 = exp2f(m_run - m), a2 = exp2f(m2 - m);  // (maxima are kept in the base-2 domain)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o_acc[dt][r] = o_acc[dt][r] * a1 + Ox[(qw * 32 + dt * 16 + r) * 64 + lane] * a2;
+    inv_l = 1.0f / (l_run * a1 + l2 * a2);
+  }
+  __syncthreads();  // Mx/Lx consumed before the staging area is overwritten
+  float* Os = smem + 4 * 32 * 64 + qw * 32 * O_LD;
+  if (kh == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        Os[l31 * O_LD + d] = o_acc[dt][r] * inv_l;
+      }
+  }
+  __syncthreads();
+  {  // both key halves store: 16 of the 32 staged rows each
+    const int64_t grow = (int64_t)b * T + q0;
+#pragma unroll
+    for (int it2 = 0; it2 < 2; ++it2) {
+      const int it = it2 + 2 * kh;
+      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8 + 4);
+      if (y) {
+        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
+        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
+      }
+      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
+    }
+  }
+#ifdef T2H_MHA_TIMING
+  if (g_mha_timing && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4)) {
+    long long* o = g_mha_timing + (wave == 4 ? 8 : 0);
+    const long long te = clock64();
+    o[0] = te - tm0; o[1] = tm1 - tm0; o[2] = tm_stage; o[3] = tm_comp; o[4] = te - tm2; o[5] = tm2 - tm1;
+  }
+#endif
+}
+
 }  // namespace
 
 extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int32_t T,
@@ -614,8 +913,15 @@ extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, cons
   dim3 grid((T / QB) * n_head * B), block(512);
   int* ovf = t2h_split_overflow_flag_ptr();
   T2H_REQUIRE(ovf != nullptr, "t2h_mha_split_f32: no overflow flag");
-  hipLaunchKernelGGL(mha_split_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt, y,
-                     y_split, T, C, n_head, ovf);
+  // T2H_MHA_PIPE=0: the register-staged kernel without the in-wave software pipeline (A/B, tests)
+  const char* const pipe_env = getenv("T2H_MHA_PIPE");
+  const bool pipe = pipe_env ? atoi(pipe_env) != 0 : T2H_MHA_PIPE_DEFAULT;
+  if (pipe)
+    hipLaunchKernelGGL(mha_split_pipe_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt,
+                       y, y_split, T, C, n_head, ovf);
+  else
+    hipLaunchKernelGGL(mha_split_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt, y,
+                       y_split, T, C, n_head, ovf);
   T2H_CHECK_LAUNCH("t2h_mha_split_f32");
   return T2H_OK;
 }

@@ -16,6 +16,10 @@ VARIANTS = (('full', []), ('full+timing', ['-DT2H_MHA_TIMING']), ('noexp', ['-DT
 if len(sys.argv) > 1 and sys.argv[1] == 'flags':
     VARIANTS = (('full', []), ('no SLP vectorizer', ['-fno-slp-vectorize']), ('no setprio', ['-DT2H_MHA_NOPRIO']),
                 ('no setprio+timing', ['-DT2H_MHA_NOPRIO', '-DT2H_MHA_TIMING']), ('full', []), ('no setprio', ['-DT2H_MHA_NOPRIO']))
+if len(sys.argv) > 1 and sys.argv[1] == 'pipe':
+    VARIANTS = (('register-staged', ['-DT2H_MHA_PIPE_DEFAULT=0']), ('pipelined + LDS-DMA', ['-DT2H_MHA_PIPE_DEFAULT=1']),
+                ('pipelined+timing', ['-DT2H_MHA_PIPE_DEFAULT=1', '-DT2H_MHA_TIMING']),
+                ('register-staged', ['-DT2H_MHA_PIPE_DEFAULT=0']), ('pipelined + LDS-DMA', ['-DT2H_MHA_PIPE_DEFAULT=1']))
 if len(sys.argv) > 1 and sys.argv[1] == 'timing':
     VARIANTS = (('full', []), ('full+timing', ['-DT2H_MHA_TIMING']), ('nomma', ['-DT2H_MDBG_NOMMA']), ('mma only', ['-DT2H_MDBG_NOEXP', '-DT2H_MDBG_NOSPLIT', '-DT2H_MDBG_NOSTAGE']))
 B, T, H, C = 8, 512, 8, 512
