@@ -652,7 +652,10 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
   const unsigned v_b16 = (unsigned)((lane & 7) ^ (lane >> 4)) * 16;   // source piece of chunk i: this ^ 64 (i & 1)
   auto dma16 = [&](unsigned voff, const char* sbase, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+#ifndef T2H_MHA_DMA_POLICY
+#define T2H_MHA_DMA_POLICY ""
+#endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" T2H_MHA_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
@@ -702,7 +705,9 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
 
   int bar_n = 0;
   const long long tm1 = TM_NOW();
+#ifndef T2H_MHA_NOPRIO
   if (kh == 1) __builtin_amdgcn_s_setprio(1);  // see mha_split_kernel
+#endif
   // ---- software pipeline over the key tiles (two (K, Vt) buffers per half, one barrier per tile):
   // the matrix pipe forms S^T of tile j + 1 while the vector ALU does the softmax of tile j -- the two
   // are independent, so the compiler interleaves them instead of the wave waiting for its own matrix

@@ -16,6 +16,10 @@ VARIANTS = (('full', []), ('full+timing', ['-DT2H_MHA_TIMING']), ('noexp', ['-DT
 if len(sys.argv) > 1 and sys.argv[1] == 'flags':
     VARIANTS = (('full', []), ('no SLP vectorizer', ['-fno-slp-vectorize']), ('no setprio', ['-DT2H_MHA_NOPRIO']),
                 ('no setprio+timing', ['-DT2H_MHA_NOPRIO', '-DT2H_MHA_TIMING']), ('full', []), ('no setprio', ['-DT2H_MHA_NOPRIO']))
+if len(sys.argv) > 1 and sys.argv[1] == 'pipe2':
+    VARIANTS = (('pipelined', []), ('pipelined, no setprio', ['-DT2H_MHA_NOPRIO']),
+                ('pipelined, nt loads', ['-DT2H_MHA_DMA_POLICY=" nt"']), ('pipelined', []),
+                ('pipelined, no setprio', ['-DT2H_MHA_NOPRIO']), ('pipelined, nt loads', ['-DT2H_MHA_DMA_POLICY=" nt"']))
 if len(sys.argv) > 1 and sys.argv[1] == 'pipe':
     VARIANTS = (('register-staged', ['-DT2H_MHA_PIPE_DEFAULT=0']), ('pipelined + LDS-DMA', ['-DT2H_MHA_PIPE_DEFAULT=1']),
                 ('pipelined+timing', ['-DT2H_MHA_PIPE_DEFAULT=1', '-DT2H_MHA_TIMING']),
