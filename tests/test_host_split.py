@@ -78,3 +78,88 @@ def test_fold_layernorm_is_the_same_affine_map_and_its_column_sums_cancel_the_me
     folded = rstd[:, None] * (x.double() @ wf.t() - mean[:, None] * cs.double()[None, :]) + bf.double()
     ref = F.layer_norm(x.double(), (C, ), gam.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
     assert (folded - ref).abs().max().item() < 2e-5                  # W' carries 22 bits
+
+
+_B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+                [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+_B128_GROUPS += [[l + 32 for l in g] for g in _B128_GROUPS]   # lanes a ds_read_b128 serves in one LDS cycle
+
+
+def _conflict_free(addr_of_lane):
+    for g in _B128_GROUPS:
+        banks = set()
+        for lane in g:
+            for d in range(4):
+                bank = (addr_of_lane(lane) // 4 + d) % 64
+                assert bank not in banks
+                banks.add(bank)
+
+
+def test_lds_dma_swizzle_algebra_of_the_attention_kernel():
+    """mha_split_pipe_kernel (csrc/attention.hip): a DMA instruction fills 1 KiB of LDS lane-linearly, so
+    the tile images are unpadded and an XOR swizzle is applied on the SOURCE piece the lane requests and
+    on the fragment read address.  This replays the kernel's index formulas: every fragment read must
+    find the piece it means, in a bank-conflict-free pattern."""
+    # K tile: 64 keys x 16 pieces of 16 B; piece p of key r at p ^ (r & 15)
+    k_slot = {}
+    for w in range(4):                       # wave of the key half
+        for i in range(4):                   # its chunks 4w + i: rows 16w + 4i + (lane >> 4)
+            for lane in range(64):
+                rr, pp = lane >> 4, lane & 15
+                r = 16 * w + 4 * i + rr
+                src_piece = (((pp ^ rr) * 16) ^ (64 * i)) // 16          # k_b16 ^ 64 i
+                lds_slot = ((4 * w + i) * 1024 + lane * 16) // 16        # lane-linear destination
+                assert lds_slot == r * 16 + pp and src_piece == pp ^ (r & 15)
+                k_slot[lds_slot] = (r, src_piece)
+    assert len(k_slot) == 64 * 16
+    for ks in range(2):
+        for kk in range(4):
+            for pl in range(2):
+                const_p = (kk >> 1) * 8 + pl * 4 + (kk & 1) * 2
+                addr = lambda lane: (ks * 32 + (lane & 31)) * 256 + ((const_p * 16) ^ (((lane >> 5) ^ (lane & 15)) * 16))
+                for lane in range(64):
+                    assert k_slot[addr(lane) // 16] == (ks * 32 + (lane & 31), const_p + (lane >> 5))
+                _conflict_free(addr)
+    # Vt tile: 128 (plane, d) rows x 8 pieces; piece p of row r at p ^ ((r >> 1) & 7)
+    v_slot = {}
+    for w in range(4):
+        for i in range(4):                   # rows 32w + 8i + (lane >> 3)
+            for lane in range(64):
+                rr, pp = lane >> 3, lane & 7
+                vr = 32 * w + 8 * i + rr
+                src_piece = (((pp ^ (lane >> 4)) * 16) ^ (64 * (i & 1))) // 16   # v_b16 ^ 64 (i & 1)
+                lds_slot = ((4 * w + i) * 1024 + lane * 16) // 16
+                assert lds_slot == vr * 8 + pp and src_piece == pp ^ ((vr >> 1) & 7)
+                v_slot[lds_slot] = (vr, src_piece)
+    assert len(v_slot) == 128 * 8
+    for pl in range(2):
+        for dt in range(2):
+            for ks in range(2):
+                for j in range(2):
+                    const_q = ks * 4 + j * 2
+                    addr = lambda lane: ((pl * 64 + dt * 32 + (lane & 31)) * 128 +
+                                         ((const_q * 16) ^ (((lane >> 5) ^ (((lane & 31) >> 1) & 7)) * 16)))
+                    for lane in range(64):
+                        assert v_slot[addr(lane) // 16] == (pl * 64 + dt * 32 + (lane & 31), const_q + (lane >> 5))
+                    _conflict_free(addr)
+
+
+def test_lds_dma_swizzle_algebra_of_the_gemm_tile_image():
+    """gemm_split_kernel<.., PP = 2> (csrc/gemm_split.hip): 8-row groups of 128-byte rows, logical piece
+    c of row r at c ^ ((r >> 1) & 7); fragment piece = plane * 4 + u * 2 + (lane >> 5)."""
+    rows = 384                                   # 256 A rows + 128 B rows of a K tile
+    slot = {}
+    for wave in range(8):
+        for i in range(rows // 64):
+            g = wave + 8 * i
+            for lane in range(64):
+                r = g * 8 + (lane >> 3)
+                pc = (lane & 7) ^ ((r >> 1) & 7)                          # source piece
+                slot[(g * 1024 + lane * 16) // 16] = (r, pc)
+    assert len(slot) == rows * 8
+    for row0 in (0, 64, 256, 320):               # wave-tile row offsets (multiples of 16)
+        for c2 in range(4):                      # c2 = plane * 2 + u
+            addr = lambda lane: (row0 + (lane & 31)) * 128 + (((c2 * 2 + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) * 16)
+            for lane in range(64):
+                assert slot[addr(lane) // 16] == (row0 + (lane & 31), c2 * 2 + (lane >> 5))
+            _conflict_free(addr)
