@@ -118,7 +118,11 @@ int t2h_gn_apply_split_f32(const float* x, int32_t ldx, const float* scale, cons
  * hh + (hl + lh) / 2048 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Operands are
  * "split rows": [rows][K/32][2][32] fp16 (128 B per row and 32-wide K tile), written
  * by t2h_split_rows_f32 / the C_split epilogue.
- * Replaces the same nn.Linear call sites as t2h_gemm_f32 (opt-in fast path). */
+ * Replaces the same nn.Linear call sites as t2h_gemm_f32 (default path of the sampler).
+ * Dispatch (automatic; t2h_gemm_split_force_config overrides): 256x128 tiles with a ping-pong LDS-DMA
+ * loop when they give >= 192 tiles, 128x64 with an in-block K split when N = 512 at M = 4096, a
+ * few-rows kernel (16x16x32 MFMA straight from global memory, K split over 8 waves) for M <= 64,
+ * 128x64 / 128x128 otherwise.  Operands must span < 2 GiB each (32-bit byte offsets). */
 typedef struct t2h_gemm_split_args {
   const uint16_t* A;      /* split rows [M][K/32][2][32] */
   const uint16_t* B;      /* split rows [N][K/32][2][32] (weights, repacked once) */
