@@ -90,8 +90,8 @@ int t2h_gemm_f32(const t2h_gemm_args* args, void* stream);
  * labels): 0 64x64, 1 128x32, 2 128x64, 3 128x128, 4 128x64/K64, 5 128x128/K64,
  * 6 128x64/8 waves, 7 128x64/K64/8 waves, 8 128x128/K64/8 waves */
 int t2h_gemm_tile_config(const t2h_gemm_args* args);
-/* tuning hook: force a configuration id for every following GEMM whose shape
- * supports it (-1 = automatic); returns the previous setting */
+/* tuning hook: force a configuration id for every following GEMM of the CALLING THREAD whose
+ * shape supports it (-1 = automatic); returns the previous setting */
 int t2h_gemm_force_config(int cfg);
 
 /* The stride-1 convolutions of the hierarchical VQGAN decode (3x3 'same', 3x3 after nearest-x2
@@ -103,7 +103,7 @@ int t2h_gemm_force_config(int cfg);
  * C, residual, bias stay fp32.  Replaces t2h_gemm_f32 at vqgan_arch.py:597-617,529-534,636-661,
  * 1000-1033,1136-1151 (opt-out: T2H_SPLIT_CONV=0). */
 int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
-int t2h_conv_split_force_tile(int rows); /* tuning / tests: 128 or 256 output pixels per tile, 0 auto; returns the old value */
+int t2h_conv_split_force_tile(int rows); /* tuning / tests (thread-local): 128 or 256 output pixels per tile, 0 auto; returns the old value */
 /* out_split[row] = split( act( x[row] * scale[img] + shift[img] ) ): GroupNorm apply (tables of
  * t2h_groupnorm_tables_f32; NULL = plain split) + swish (act 1) of fp32 NHWC rows in one pass
  * (vqgan_arch.py:510-517,599-600,609-610,637,1026-1027) */
@@ -141,30 +141,20 @@ typedef struct t2h_gemm_split_args {
    * P*V matrix instruction contracts them.  NULL = off. */
   uint16_t* Vt;
   int32_t vt_col0, vt_T, vt_hd;
-  /* LayerNorm folded into the two Linears either side of it (transformer_arch.py:93-95: x + mlp(ln2(x)),
-   * x + attn(ln1(x))): no LayerNorm launch, no normalised copy of the activations.
-   *   producer (proj / fc2, which write the residual stream x): ln_part_out[M][N/32][2] receives, per row
-   *     and 32-column slice of the FINAL output values, (mean, sum of squared deviations from that mean);
-   *     C_split then carries split(x) for the consumer.  Needs N % 32 == 0, not combined with Vt.
-   *   consumer (q|k|v / fc1 with B = W diag(gamma), bias = b + W beta, both folded on the host):
-   *     ln_part_in[M][K/32][2] are the partials of A's rows (A = split(x), NOT normalised),
-   *     ln_colsum[N] = sum_k B[n][k] of the split-rounded weights; the epilogue evaluates
-   *     rstd_m (acc[m][n] - mean_m ln_colsum[n]) + bias[n] with (mean, rstd) from a fixed-order
-   *     (Chan) combination of the row's partials, eps = ln_eps.  NULL = off. */
-  float* ln_part_out;
-  const float* ln_part_in;
-  const float* ln_colsum;
-  float ln_eps;
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
 /* Sticky device-side overflow flag of every split-row producer (this GEMM's C_split / Vt
- * epilogues, t2h_split_rows_f32, t2h_layernorm_split_f32, the attention outputs): raised when a
- * value about to be written as split rows has |x| >= 65504 (fp16 planes would hold inf / NaN).
- * Synchronises `stream`, returns 1 if the flag was raised since the last reset, 0 if not, < 0 on
- * error; reset != 0 clears it.  The host side checks it once per sampling run and raises. */
+ * epilogues, t2h_split_rows_f32, t2h_layernorm_split_f32, t2h_gn_apply_split_f32, the attention
+ * outputs): raised when a value about to be written as split rows has |x| >= 65504 (fp16 planes
+ * would hold inf / NaN).  There is one flag PER (device, stream): a producer raises the flag of the
+ * stream it was launched on, so two models driven on two streams (or threads) neither see nor clear
+ * each other's state.  Synchronises `stream`, returns 1 if that stream's flag was raised since its
+ * last reset, 0 if not, < 0 on error; reset != 0 clears it.  The host side clears it at the start of a
+ * sampling run / decode and checks it at the end. */
 int t2h_split_overflow(int32_t reset, void* stream);
-int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..6, 8 (ping-pong LDS-DMA), 9 (few-rows kernel), -1 auto */
+int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..3, 5, 6, 8 (ping-pong LDS-DMA), 9 (few-rows kernel), -1 auto;
+                                              thread-local: it affects launches of the calling thread only */
 /* fp32 [rows, C] (row stride ldx) -> split rows */
 int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);
 /* producers that emit split rows directly: LayerNorm (transformer_arch.py:93-95)
@@ -266,6 +256,14 @@ typedef struct t2h_sample_heads_args {
   uint64_t philox_seed;
   uint64_t philox_offset[T2H_MAX_HEADS];
   uint32_t philox_grid_threads;
+  /* per-LISTED-ROW noise (needs logits_ws), for row lists that mix sampling steps (the schedule of
+   * t2h_unmask_schedule regrouped so that every sample advances through its own active steps):
+   * row_philox_offset[i] = generator offset of the exponential_ draw that rows[i]'s head makes at
+   * rows[i]'s step (replaces philox_offset[head]; needs philox_grid_threads), or
+   * expo_rows[(expo_slot ? expo_slot[i] : i)][n_class] = that row of the explicit draw.  NULL = off. */
+  const uint64_t* row_philox_offset;
+  const float* expo_rows;
+  const int32_t* expo_slot;
 } t2h_sample_heads_args;
 /* dst[i] = src[rows[i]], rows of row_bytes (multiple of 16) bytes */
 int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, int32_t n_rows, int32_t row_bytes, void* stream);
@@ -273,6 +271,24 @@ int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, int32_t n_r
  * (seed, offset as the generator holds them BEFORE the draw; grid_threads as above) */
 int t2h_philox_exponential_f32(uint64_t seed, uint64_t offset, uint32_t grid_threads, float* out, int64_t numel,
                                void* stream);
+/* the same for `torch.rand(numel)` (uniform_(0, 1): curand_uniform with the bounds reversed, 1 -> 0) */
+int t2h_philox_uniform_f32(uint64_t seed, uint64_t offset, uint32_t grid_threads, float* out, int64_t numel,
+                           void* stream);
+/* The whole unmasking schedule of one sample_fn call (models/sample_model.py:279-292,301-306) in one
+ * launch: the schedule depends on the `rand([B,T])` draws only, never on the transformer, and the
+ * generator offset of every draw only on how many heads sampled at the earlier steps.  Reproduces
+ * the `steps` rand draws of torch's device generator (seed, `offset` = its offset before the first
+ * draw; rand_grid_threads / rand_inc = ATen's grid and offset increment for an n-element draw,
+ * expo_inc = the increment of one [n, n_class] exponential_ draw) and writes
+ *   step_of_row[n]        the step t (steps .. 1) at which token row i is unmasked,
+ *   head_mask[steps + 1]  bit h of head_mask[t] set iff a token of texture h is unmasked at step t
+ * (head_mask[0] = 0).  The generator offset before the rand of step t is then
+ * offset + sum over s > t of (rand_inc + popcount(head_mask[s]) * expo_inc); the exponential_ draw
+ * of the i-th active head (ascending) at step t starts rand_inc + i * expo_inc after it.
+ * steps <= 4096, n_heads <= 32. */
+int t2h_unmask_schedule(uint64_t seed, uint64_t offset, uint32_t rand_grid_threads, uint32_t rand_inc,
+                        uint32_t expo_inc, const int64_t* tex, int32_t n, int32_t steps, int32_t n_heads,
+                        int32_t* step_of_row, uint32_t* head_mask, void* stream);
 int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream);
 
 /* Sampler training-time forward (models/transformer_model.py:212-274, forward only).

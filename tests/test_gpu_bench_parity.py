@@ -21,6 +21,10 @@ accounted for explicitly: with the step's noise re-drawn from the recorded gener
 AND dl is inside the activation tolerance.  Counts are REPORTED (gpurun_out/ JSON + the
 assertion message), never asserted away.
 
+Both schedules of engine.sample_tokens are forced this way: the reference's synchronous steps, and the
+product path's default in which every sample advances through its own active steps (a round then
+holds samples at different steps; engine.sample_tokens docstring).
+
 Variants: (a) synthetic default weights; (b) the peaked-logits variant SURVEY.md 8(d)
 prescribes (`head_list.*` x50, `conv_seg_head_list.*` x50), where decision margins look
 like a trained model's and a logit error is NOT drowned by the noise.  Both the default
@@ -69,22 +73,37 @@ def _oracle_run(model, sd_dev, batch):
     return ref, {d['t']: d for d in trace}, noise.state
 
 
-def _forced_run(model, trace):
-    """HIP sampler on the oracle's trajectory; -> list of (t, row, ours, oracle's)."""
-    mism = []
+def _forced_run(model, trace, compact):
+    """HIP sampler on the oracle's trajectory; -> list of (t, row, ours, oracle's).
 
-    def hook(t, x_t, out):
+    compact=False: one round per step, all samples at that step (the reference's loop).
+    compact=True (the default schedule of the product path): every sample walks through its OWN
+    active steps, so a round holds samples at different steps; sample b at step t must agree with --
+    and is then forced to -- the oracle's state of sample b after step t."""
+    mism = []
+    T = trace[STEPS]['x_t'].shape[1]
+
+    def step_hook(t, x_t, out):
         want = trace[t]['x_t']
         bad = (x_t != want).nonzero()
         for b, j in bad.tolist():
-            mism.append((t, b * x_t.shape[1] + j, int(x_t[b, j]), int(want[b, j])))
+            mism.append((t, b * T + j, int(x_t[b, j]), int(want[b, j])))
         x_t.copy_(want)
+
+    def round_hook(r, steps, x_t, out):
+        for b, t in enumerate(steps.tolist()):
+            if t == 0:
+                continue                                    # idle in this round: nothing was sampled
+            want = trace[t]['x_t'][b]
+            for j in (x_t[b] != want).nonzero().flatten().tolist():
+                mism.append((t, b * T + j, int(x_t[b, j]), int(want[j])))
+            x_t[b].copy_(want)
 
     _seed(SEED)
     tex_tok = model._texture_tokens(model.texture_mask)
-    engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, STEPS, model.mask_id,
-                         step_hook=hook)
-    return mism
+    kw = dict(round_hook=round_hook, compact=True) if compact else dict(step_hook=step_hook)
+    engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, STEPS, model.mask_id, **kw)
+    return mism, dict(model.sampler_fn.last_stats)
 
 
 def _account(model, sd_dev, batch, trace, rng_state, mism, scale):
@@ -134,12 +153,18 @@ def test_bench_config_parity(peaked, monkeypatch):
 
     exact = engine.SamplerNet(model.P, model._tf_desc, opt['bert_n_head'], 'tf', split=False)
     split = model.sampler_fn
-    for name, net in (('split_2xfp16', split), ('exact_fp32', exact)):
+    for name, net, compact in (('split_2xfp16', split, True), ('split_2xfp16_synchronous_steps', split, False),
+                               ('exact_fp32', exact, True)):
         model.sampler_fn = net
-        mism = _forced_run(model, trace)
+        mism, stats = _forced_run(model, trace, compact)
         acc = _account(model, sd_dev, batch, trace, rng_state, mism, scale)
-        report['paths'][name] = dict(decisions=B * 512, mismatches=len(mism), accounted=acc)
+        report['paths'][name] = dict(decisions=B * 512, mismatches=len(mism), accounted=acc, schedule=stats)
     model.sampler_fn = split
+    st = report['paths']['split_2xfp16']['schedule']
+    # a (sample, step) pair is evaluated iff it changes a token; ~13.5 % of them change none
+    assert st['sample_steps_needed'] < 0.9 * st['sample_steps_possible'] and st['rounds'] < STEPS
+    assert report['paths']['split_2xfp16_synchronous_steps']['schedule']['rounds'] == len(
+        [t for t in trace if trace[t]['active']])
 
     # free-running (not teacher-forced) runs of both product paths: what bench.py compares
     free = {}

@@ -119,3 +119,86 @@ def test_argument_validation_raises():
         ops.mha_noncausal(torch.zeros(2 * 100, 1536, device=DEV), 2, 100, 8)
     with pytest.raises(T2HError, match='unsupported'):
         ops.layernorm(torch.zeros(8, 384, device=DEV), torch.ones(384, device=DEV), torch.zeros(384, device=DEV))
+
+
+@pytest.mark.parametrize('noise', ['torch_device_generator', 'explicit_cpu_draws'])
+def test_compact_rounds_give_the_synchronous_loops_tokens(model, monkeypatch, noise):
+    """engine.sample_tokens: every sample walking through its OWN active steps (the default) samples
+    exactly the tokens of the reference's synchronous loop -- for the in-kernel Philox reproduction of
+    torch's draws and for explicit draws -- with fewer transformer evaluations; the torch generator
+    ends at the same offset either way."""
+    from text2human_amd import engine
+    batch = synthetic.parsing_batch(3, seed=31)
+    model.feed_data(batch)
+    tex_tok = model._texture_tokens(model.texture_mask)
+    runs, stats, ends = {}, {}, {}
+    for compact in (True, False):
+        torch.cuda.manual_seed_all(123)
+        nz = R.SeededNoise(5, 'cpu') if noise == 'explicit_cpu_draws' else None
+        runs[compact] = engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, 40,
+                                             model.mask_id, noise=nz, compact=compact).clone()
+        stats[compact] = dict(model.sampler_fn.last_stats)
+        ends[compact] = torch.cuda.default_generators[torch.cuda.current_device()].get_offset()
+    assert torch.equal(runs[True], runs[False])
+    assert ((runs[True] >= 0).sum(0) == 1).all()                      # every token sampled once, by one head
+    assert ends[True] == ends[False]
+    assert stats[True]['sample_steps_needed'] == stats[False]['sample_steps_needed']
+    assert stats[True]['rounds'] <= stats[False]['rounds'] <= 40
+    assert stats[True]['sample_steps_launched'] >= stats[True]['sample_steps_needed']
+    if noise == 'torch_device_generator':                             # and T2H_COMPACT_ROUNDS=0 selects the other one
+        monkeypatch.setenv('T2H_COMPACT_ROUNDS', '0')
+        torch.cuda.manual_seed_all(123)
+        again = engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, 40, model.mask_id)
+        assert model.sampler_fn.last_stats['rounds'] == stats[False]['rounds'] and torch.equal(again, runs[False])
+
+
+def test_emulated_torch_draws_fall_back_to_real_ones(model, monkeypatch):
+    """If the in-kernel reproduction of ATen's Philox kernels ever disagreed with the installed torch
+    (TorchDeviceNoise.emulation_ok), the schedule is built from real torch draws: same tokens, same
+    final generator offset."""
+    from text2human_amd import engine
+    model.feed_data(synthetic.parsing_batch(2, seed=32))
+    tex_tok = model._texture_tokens(model.texture_mask)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    torch.cuda.manual_seed_all(7)
+    a = engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, 12, model.mask_id).clone()
+    end_a = gen.get_offset()
+    monkeypatch.setattr(engine.TorchDeviceNoise, 'emulation_ok', lambda self, n, k: False)
+    torch.cuda.manual_seed_all(7)
+    b = engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, 12, model.mask_id)
+    assert torch.equal(a, b) and gen.get_offset() == end_a
+
+
+def test_stale_overflow_flag_is_not_this_runs_and_decode_checks_its_own(opt, sds, model):
+    """The sticky split-overflow flag: a flag left by an earlier producer must not fail the next valid
+    sampling run, and a decoder activation outside fp16's range must raise from decode_indices, naming
+    the decode stage."""
+    from text2human_amd import engine
+    model.feed_data(synthetic.parsing_batch(1, seed=33))
+    ops.split_rows(torch.full((32, 64), 1.0e5, device=DEV))          # raises the flag of this stream
+    top = model.sample_fn(temp=1, sample_steps=2)                     # ... which sample_fn clears at its start
+    assert not ops.split_overflow(reset=False)
+    model.decode_indices(top)
+    bad = {k: dict(v) for k, v in sds.items()}
+    bad['top_post_quant_conv']['weight'] = sds['top_post_quant_conv']['weight'] * 1.0e7
+    m2 = SampleFromParsingModel(opt, state_dicts=bad)
+    m2.feed_data(synthetic.parsing_batch(1, seed=33))
+    with pytest.raises(engine.SplitOverflowError, match='VQGAN refine / decode.*T2H_SPLIT_CONV'):
+        m2.decode_indices(top)
+    assert not ops.split_overflow(reset=True)
+
+
+def test_last_layer_trim_on_and_off_sample_the_same_tokens_on_the_bench_config(monkeypatch):
+    """T2H_TRIM_LAST_LAYER: the last layer's row-wise tail on the changed rows only (few-rows GEMM
+    kernel, another summation order) vs on all rows -- equal to rounding, so the tokens of the
+    benchmarked configuration (B = 8, 256 steps, seed 2021) must agree up to float near-ties; on the
+    synthetic default weights (noise-decided races) none is expected."""
+    opt = options.dict_to_nonedict(defaults.sample_from_parsing())
+    model = SampleFromParsingModel(opt, state_dicts=synthetic.make_state_dicts(opt, seed=1234))
+    model.feed_data(synthetic.parsing_batch(8, seed=2021))
+    toks = {}
+    for trim in ('1', '0'):
+        monkeypatch.setenv('T2H_TRIM_LAST_LAYER', trim)
+        options.set_random_seed(2021)
+        toks[trim] = torch.stack(model.sample_fn(temp=1, sample_steps=256))
+    assert int((toks['1'] != toks['0']).sum()) == 0

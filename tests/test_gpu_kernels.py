@@ -317,13 +317,98 @@ def test_sample_heads_philox_mode_equals_explicit_draws():
     expo = {h: noise.exponential(1, h, (n, K)) for h in active}
     x_a, out_a = torch.full((n, ), 18432, dtype=torch.int64, device=DEV), torch.full((H, n), -1, dtype=torch.int64, device=DEV)
     ops.sample_heads(hidden, g, b, w, expo, rows, rows.numel(), texd, 1.0, x_a, out_a)
-    end_state = torch.cuda.get_rng_state()
+    end_off = noise.generator()[0].get_offset()
     torch.cuda.manual_seed_all(77)
-    philox = noise.reserve_exponential(active, (n, K))
-    assert torch.equal(torch.cuda.get_rng_state(), end_state)   # the generator moved exactly as far
+    gen = noise.generator()[0]
+    _, inc = ops.torch_draw_geometry(n * K)
+    philox = (gen.initial_seed(), {h: gen.get_offset() + i * inc for i, h in enumerate(active)})
+    assert gen.get_offset() + len(active) * inc == end_off         # the draws moved the generator exactly that far
     x_b, out_b = torch.full_like(x_a, 18432), torch.full_like(out_a, -1)
     ops.sample_heads(hidden, g, b, w, {}, rows, rows.numel(), texd, 1.0, x_b, out_b, philox=philox)
     assert torch.equal(x_a, x_b) and torch.equal(out_a, out_b)
+    # per-listed-row noise (row lists that mix sampling steps): offsets per row, explicit compact rows
+    offs = torch.tensor([philox[1][int(tex[r])] for r in rows.cpu().tolist()], dtype=torch.int64, device=DEV)
+    x_c, out_c = torch.full_like(x_a, 18432), torch.full_like(out_a, -1)
+    ops.sample_heads(hidden, g, b, w, {}, rows, rows.numel(), texd, 1.0, x_c, out_c, row_noise=('philox', philox[0], offs))
+    assert torch.equal(x_a, x_c) and torch.equal(out_a, out_c)
+    perm = torch.randperm(rows.numel(), generator=gen_c)
+    erows = torch.empty(rows.numel(), K, device=DEV)
+    for i, r in enumerate(rows.cpu().tolist()):
+        erows[int(perm[i])] = expo[int(tex[r])][r]
+    x_d, out_d = torch.full_like(x_a, 18432), torch.full_like(out_a, -1)
+    ops.sample_heads(hidden, g, b, w, {}, rows, rows.numel(), texd, 1.0, x_d, out_d,
+                     row_noise=('explicit', erows, perm.to(torch.int32).to(DEV)))
+    assert torch.equal(x_a, x_d) and torch.equal(out_a, out_d)
+
+
+@pytest.mark.parametrize('n', [4096, 16384, 512, 3 * 512 + 7])
+def test_philox_uniform_is_torchs_rand_bit_for_bit(n):
+    """t2h_philox_uniform_f32 == torch.rand(n) on the device generator, at several offsets."""
+    torch.cuda.manual_seed_all(4242 + n)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    torch.empty(1000, device=DEV).exponential_(1.0)        # move the offset off zero
+    for _ in range(3):
+        seed, off = gen.initial_seed(), gen.get_offset()
+        ref = torch.rand(n // 512, 512, device=DEV) if n % 512 == 0 else torch.rand(n, device=DEV)
+        _, inc = ops.torch_draw_geometry(n)
+        assert gen.get_offset() == off + inc
+        got = ops.philox_uniform(seed, off, n, DEV)
+        assert torch.equal(got, ref.reshape(-1)), f'{int((got != ref.reshape(-1)).sum())} of {n} elements differ'
+    assert float(got.min()) >= 0.0 and float(got.max()) < 1.0
+
+
+@pytest.mark.parametrize('B,steps', [(8, 256), (3, 17), (32, 256), (1, 1)])
+def test_unmask_schedule_replays_the_reference_loop(B, steps):
+    """t2h_unmask_schedule (one launch, no transformer) == the reference's loop over real torch draws
+    (models/sample_model.py:279-306): same step for every token, same active heads per step, and the
+    generator ends where the reference's would."""
+    from text2human_amd import engine, schedule
+    T, H, K = 512, 18, 1024
+    n = B * T
+    gen_c = torch.Generator().manual_seed(B * 1000 + steps)
+    tex = torch.randint(0, H, (B, T), generator=gen_c)
+    tex[tex == 5] = 6                                      # a head that never samples
+    texd = tex.to(DEV)
+    torch.cuda.manual_seed_all(99)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    # reference loop on real draws
+    unmasked = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    want_step = torch.zeros(n, dtype=torch.int32, device=DEV)
+    want_mask = [0] * (steps + 1)
+    for t in range(steps, 0, -1):
+        ch = torch.rand((B, T), device=DEV) < 1 / torch.tensor(float(t), device=DEV)
+        ch = torch.bitwise_xor(ch, torch.bitwise_and(ch, unmasked))
+        unmasked |= ch
+        want_step[ch.view(-1)] = t
+        for h in range(H):
+            if int((texd.view(-1)[ch.view(-1)] == h).sum()) > 0:
+                want_mask[t] |= 1 << h
+                torch.empty((n, K), device=DEV).exponential_(1.0)
+    end_off = gen.get_offset()
+    # the product path's schedule on a re-seeded generator
+    torch.cuda.manual_seed_all(99)
+    noise = engine.TorchDeviceNoise(DEV)
+    assert noise.emulation_ok(n, K)
+    sched = engine.build_schedule(texd, steps, H, K, noise, compact=True)
+    assert gen.get_offset() == end_off
+    step_dev, mask_dev, rand_inc, expo_inc = ops.unmask_schedule(gen.initial_seed(), 0, texd.view(-1).contiguous(), steps, H, K)
+    assert torch.equal(step_dev, want_step)
+    assert mask_dev.cpu().tolist()[1:] == want_mask[1:]
+    # rounds: every row once, each sample walks its own steps in descending order, offsets of the row's head
+    rows = sched.rows.cpu().long()
+    assert torch.equal(rows.sort().values, torch.arange(n))
+    _, expo_off, final = schedule.draw_offsets(want_mask, steps, 0, rand_inc, expo_inc, H)
+    assert final == end_off
+    ws = want_step.cpu()
+    for r in range(sched.n_rounds):
+        rr = rows[int(sched.start[r]):int(sched.start[r + 1])]
+        for b in range(B):
+            mine = rr[(rr // T) == b]
+            t_b = int(sched.round_steps[r, b])
+            assert (ws[mine] == t_b).all() if t_b else mine.numel() == 0
+    offs = sched.offsets.cpu()
+    assert torch.equal(offs, torch.from_numpy(expo_off)[ws[rows].long(), tex.view(-1)[rows]])
+    assert sched.n_rounds <= steps and (sched.round_steps > 0).sum() == sum(len(set(ws.view(B, T)[b].tolist())) for b in range(B))
 
 
 # ------------------------------------------------------------------ quantizer pieces

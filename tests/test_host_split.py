@@ -52,34 +52,6 @@ def test_out_of_range_weights_are_rejected_loudly():
         ops.pack_split_rows_host(torch.full((32, 32), 7.0e4))
 
 
-def test_fold_layernorm_is_the_same_affine_map_and_its_column_sums_cancel_the_mean():
-    """weights.fold_layernorm (t2h_gemm_split_args.ln_part_in): rstd (x W'^T - mean colsum) + b' with the
-    split-rounded W' is LayerNorm(x) W^T + b; the (mean, M2) partials combine to the row moments the way
-    the kernel's prologue does (Chan et al.)."""
-    import torch.nn.functional as F
-    from text2human_amd import weights
-    g = torch.Generator().manual_seed(5)
-    C, N, M = 512, 96, 40
-    x = torch.randn(M, C, generator=g) * 3.0 + torch.randn(M, 1, generator=g) * 2.0
-    w, b = torch.randn(N, C, generator=g) * 0.05, torch.randn(N, generator=g)
-    gam, beta = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.3
-    wf_split, cs, bf = weights.fold_layernorm(w, b, gam, beta)
-    wf = ops.unsplit_rows_host(wf_split, N, C).double()
-    assert (cs.double() - wf.sum(1)).abs().max().item() < 1e-6      # fp32 rounding of the fp64 sum
-    # partials per 32 columns -> row moments
-    xc = x.double().view(M, C // 32, 32)
-    mu_i = xc.mean(-1)
-    m2_i = ((xc - mu_i[..., None]) ** 2).sum(-1)
-    mean = mu_i.mean(-1)
-    var = (m2_i.sum(-1) + 32.0 * ((mu_i - mean[:, None]) ** 2).sum(-1)) / C
-    assert (mean - x.double().mean(-1)).abs().max().item() < 1e-12
-    assert (var - x.double().var(-1, unbiased=False)).abs().max().item() < 1e-10
-    rstd = 1.0 / torch.sqrt(var + 1e-5)
-    folded = rstd[:, None] * (x.double() @ wf.t() - mean[:, None] * cs.double()[None, :]) + bf.double()
-    ref = F.layer_norm(x.double(), (C, ), gam.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
-    assert (folded - ref).abs().max().item() < 2e-5                  # W' carries 22 bits
-
-
 _B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
                 [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
 _B128_GROUPS += [[l + 32 for l in g] for g in _B128_GROUPS]   # lanes a ds_read_b128 serves in one LDS cycle

@@ -1,0 +1,70 @@
+"""Host-side bookkeeping of the sampling schedule (text2human_amd/schedule.py): CPU, numpy only."""
+import numpy as np
+import pytest
+
+from text2human_amd import schedule
+
+
+def _random_schedule(B, T, steps, seed):
+    """step of every token as the reference's loop would assign it (uniform thresholds 1/t)"""
+    rng = np.random.default_rng(seed)
+    step = np.zeros(B * T, dtype=np.int64)
+    for t in range(steps, 0, -1):
+        hit = (rng.random(B * T) < np.float32(1.0) / np.float32(t)) & (step == 0)
+        step[hit] = t
+    assert (step > 0).all()
+    return step
+
+
+@pytest.mark.parametrize('B,T,steps', [(8, 512, 256), (1, 512, 5), (3, 64, 1), (32, 512, 256)])
+def test_compact_rounds_cover_every_row_once_and_keep_each_samples_order(B, T, steps):
+    step = _random_schedule(B, T, steps, seed=B * 7 + steps)
+    order, start, round_steps = schedule.group_rounds(step, B, T, compact=True)
+    assert sorted(order.tolist()) == list(range(B * T))
+    R = len(start) - 1
+    assert start[0] == 0 and start[-1] == B * T and round_steps.shape == (R, B)
+    for b in range(B):
+        mine = np.unique(step[b * T:(b + 1) * T])[::-1]
+        assert round_steps[:len(mine), b].tolist() == mine.tolist()      # descending t, no gaps
+        assert (round_steps[len(mine):, b] == 0).all()
+    for r in range(R):
+        rows = order[start[r]:start[r + 1]]
+        assert (np.diff(rows) > 0).all()                                # sorted by row inside a round
+        assert (step[rows] == round_steps[r, rows // T]).all()
+    st = schedule.stats(round_steps, steps)
+    assert st['sample_steps_needed'] == sum(len(np.unique(step[b * T:(b + 1) * T])) for b in range(B))
+    assert st['rounds'] == max(len(np.unique(step[b * T:(b + 1) * T])) for b in range(B)) <= steps
+    if steps == 256 and T == 512:   # P(no change) = (1 - 1/t)^(masked) ~ exp(-2): 13.5 % of the pairs
+        assert 0.84 < st['sample_steps_needed'] / st['sample_steps_possible'] < 0.89
+
+
+def test_synchronous_rounds_are_the_reference_loop_minus_empty_steps():
+    B, T, steps = 4, 128, 60
+    step = _random_schedule(B, T, steps, seed=3)
+    order, start, round_steps = schedule.group_rounds(step, B, T, compact=False)
+    active = np.unique(step)[::-1]
+    assert len(start) - 1 == len(active)
+    for r, t in enumerate(active):
+        rows = order[start[r]:start[r + 1]]
+        assert (step[rows] == t).all() and len(rows) == (step == t).sum()
+        for b in range(B):
+            assert round_steps[r, b] == (t if (step[b * T:(b + 1) * T] == t).any() else 0)
+
+
+def test_draw_offsets_follow_the_generator():
+    steps, H = 6, 18
+    mask = np.zeros(steps + 1, dtype=np.int64)
+    mask[6], mask[5], mask[3], mask[1] = 0b101, 0, 1 << 17, 0b11
+    rand_off, expo_off, final = schedule.draw_offsets(mask, steps, 40, 4, 4096, H)
+    assert rand_off[6] == 40 and expo_off[6, 0] == 44 and expo_off[6, 2] == 44 + 4096
+    assert rand_off[5] == 44 + 2 * 4096 and (expo_off[5] == -1).all()
+    assert rand_off[4] == rand_off[5] + 4 and rand_off[3] == rand_off[4] + 4
+    assert expo_off[3, 17] == rand_off[3] + 4 and rand_off[2] == rand_off[3] + 4 + 4096
+    assert expo_off[1, 0] == rand_off[1] + 4 and expo_off[1, 1] == rand_off[1] + 4 + 4096
+    assert final == rand_off[1] + 4 + 2 * 4096
+    assert (expo_off[[6, 3, 1]] >= 0).sum() == 5
+
+
+def test_group_rounds_rejects_rows_without_a_step():
+    with pytest.raises(ValueError):
+        schedule.group_rounds(np.array([1, 0, 2, 1]), 1, 4)

@@ -42,7 +42,6 @@ class GemmSplitArgs(ctypes.Structure):
         ('A', c_vp), ('B', c_vp), ('C', c_vp), ('C_split', c_vp), ('bias', c_vp), ('residual', c_vp),
         ('M', c_i32), ('N', c_i32), ('K', c_i32), ('ldc', c_i32), ('ldr', c_i32), ('epi_act', c_i32),
         ('Vt', c_vp), ('vt_col0', c_i32), ('vt_T', c_i32), ('vt_hd', c_i32),
-        ('ln_part_out', c_vp), ('ln_part_in', c_vp), ('ln_colsum', c_vp), ('ln_eps', c_f32),
     ]
 
 
@@ -58,6 +57,7 @@ class SampleHeadsArgs(ctypes.Structure):
         ('logits_ws', c_vp), ('hidden_compact', c_i32),
         ('philox_seed', ctypes.c_uint64), ('philox_offset', ctypes.c_uint64 * MAX_HEADS),
         ('philox_grid_threads', ctypes.c_uint32),
+        ('row_philox_offset', c_vp), ('expo_rows', c_vp), ('expo_slot', c_vp),
     ]
 
 
@@ -90,6 +90,9 @@ SIGNATURES = {
     't2h_sample_heads': (ctypes.c_int, [ctypes.POINTER(SampleHeadsArgs), c_vp]),
     't2h_gather_rows': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     't2h_philox_exponential_f32': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, c_vp, c_i64, c_vp]),
+    't2h_philox_uniform_f32': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, c_vp, c_i64, c_vp]),
+    't2h_unmask_schedule': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                           ctypes.c_uint32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     't2h_q_sample': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp]),
     't2h_masked_ce_heads': (ctypes.c_int, [c_vp] * 9 + [c_i32] * 5 + [c_vp]),
     't2h_sample_head': (ctypes.c_int, [c_vp] * 7 + [c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -27,10 +27,6 @@
 
 #include "common.h"
 
-#ifndef T2H_MHA_PIPE_DEFAULT
-#define T2H_MHA_PIPE_DEFAULT 1
-#endif
-
 namespace {
 
 constexpr int HD = 64;       // head dim
@@ -238,12 +234,6 @@ __global__ __launch_bounds__(512) void mha_kernel(const float* __restrict__ qkv,
 typedef t2h_f16x8 f16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SK_ROW = 272;                      // K tile row in LDS: 2 x 128 B + 16 (17 slots, odd)
-constexpr int SV_ROW = 144;                      // Vt tile row in LDS: 64 keys x 2 B + 16 (9 slots, odd)
-constexpr int SK_TILE = KT * SK_ROW;             // 17408 B
-constexpr int SV_TILE = 2 * HD * SV_ROW;         // 18432 B
-constexpr int SKV_TILE = SK_TILE + SV_TILE;      // per key half
-
 template <int J>
 __device__ __forceinline__ void split8(const f32x16& x, f16x8& hi, f16x8& lo) {
 #pragma unroll
@@ -274,309 +264,7 @@ __device__ __forceinline__ void half_barrier(int* ctr, int target, int lane) {
   asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(512) void mha_split_kernel(const uint16_t* __restrict__ qk, int ld_cols,
-                                                        const uint16_t* __restrict__ vt, float* __restrict__ y,
-                                                        uint16_t* __restrict__ y_split, int T, int C, int n_head,
-                                                        int* ovf) {
-  // two (K, Vt) tile pairs per key half (double buffer); reused at the end for the merge + output
-  // transpose staging
-  constexpr int SMEM_B = 4 * SKV_TILE > (4 * 32 * 64 + 4 * 32 * O_LD) * 4 ? 4 * SKV_TILE
-                                                                           : (4 * 32 * 64 + 4 * 32 * O_LD) * 4;
-  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_B + 16];
-  float* const smem = reinterpret_cast<float*>(smem_raw);
-  int* const bar = reinterpret_cast<int*>(smem_raw + SMEM_B);  // one counter per key half
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform values in scalar registers
-  const long long tm0 = TM_NOW();
-  long long tm_stage = 0, tm_comp = 0;
-  if (tid < 2) bar[tid] = 0;
-  __syncthreads();
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int qw = wave & 3, kh = wave >> 2;
-  int qt, head, b;
-  {
-    const int nqt = T / QB, total = gridDim.x, id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    qt = lin % nqt;
-    const int hb = lin / nqt;
-    head = hb % n_head;
-    b = hb / n_head;
-  }
-  const int q0 = qt * QB + qw * 32;
-  const int64_t row_b = (int64_t)(ld_cols / 32) * T2H_SPLIT_TILE_B;  // bytes per split row
-  const char* const qk_b = reinterpret_cast<const char*>(qk) + (int64_t)b * T * row_b;
-  const int q_tile0 = 2 * head, k_tile0 = C / 32 + 2 * head;  // 32-column tiles of this head's q / k
-
-  // Q fragments: k16-step kk covers d = 16 kk + 8 h .. + 7 of plane pl
-  f16x8 qf[4][2];
-  {
-    const char* qp = qk_b + (int64_t)(q0 + l31) * row_b + q_tile0 * T2H_SPLIT_TILE_B + hh * 16;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        qf[kk][pl] = *reinterpret_cast<const f16x8*>(qp + (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
-  }
-
-  f32x16 o_acc[2], o_lo[2];  // O^T = o_acc + 2^-11 o_lo (hi*hi and the cross products)
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[dt][r] = o_lo[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  // staging per key half (256 threads): K tile = 64 keys x 16 pieces (thread: key s_t/4,
-  // pieces (s_t&3) + 4i), Vt tile = 128 (plane, d) rows x 8 pieces (thread: row s_t/8 + 32i,
-  // piece s_t&7): 4 + 4 16-byte pieces per thread, addresses affine in i
-  const int s_half = wave >> 2, s_t = tid & 255;
-  const int half_keys = T / 2;
-  char* const Ks_st = smem_raw + s_half * (2 * SKV_TILE);  // + buf * SKV_TILE
-  char* const Vs_st = Ks_st + SK_TILE;
-  const char* const vt_b = reinterpret_cast<const char*>(vt) + ((int64_t)(b * n_head + head) * 2 * HD) * T * 2;
-  const char* const ksrc = qk_b + (int64_t)(s_half * half_keys + (s_t >> 2)) * row_b +
-                           k_tile0 * T2H_SPLIT_TILE_B + (s_t & 3) * 16;
-  const int kdst = (s_t >> 2) * SK_ROW + (s_t & 3) * 16;
-  const char* const vsrc = vt_b + ((int64_t)(s_t >> 3) * T + s_half * half_keys) * 2 + (s_t & 7) * 16;
-  const int vdst = (s_t >> 3) * SV_ROW + (s_t & 7) * 16;
-  const int64_t v_step = (int64_t)32 * T * 2;  // 32 (plane, d) rows further
-  u32x4 kreg[4], vreg[4];
-  auto load_kv = [&](int it) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      kreg[i] = *reinterpret_cast<const u32x4*>(ksrc + (int64_t)it * KT * row_b + i * 64);
-      vreg[i] = *reinterpret_cast<const u32x4*>(vsrc + it * KT * 2 + i * v_step);
-    }
-  };
-  auto store_kv = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(Ks_st + buf * SKV_TILE + kdst + i * 64) = kreg[i];
-      *reinterpret_cast<u32x4*>(Vs_st + buf * SKV_TILE + vdst + i * 32 * SV_ROW) = vreg[i];
-    }
-  };
-
-  // partial products (A plane, B plane): (l,h) (h,l) -> the 2^-11 accumulator, (h,h) -> the main one
-  constexpr int PA[3] = {1, 0, 0};
-  constexpr int PB[3] = {0, 1, 0};
-
-  const char* const Ks0 = smem_raw + kh * (2 * SKV_TILE);
-  const int nit = half_keys / KT;
-  load_kv(0);
-  // staging threads [0,256) are waves 0-3 = key half 0, [256,512) waves 4-7 = half 1, so a
-  // half stages exactly the tiles its own waves read (s_half == kh)
-  int bar_n = 0;
-  const long long tm1 = TM_NOW();
-  // the second-dispatched half of the workgroup loses every issue arbitration against its older SIMD
-  // partner (measured: its loop took 37k cycles against 26k): static priority evens the two out
-#ifndef T2H_MHA_NOPRIO
-  if (kh == 1) __builtin_amdgcn_s_setprio(1);
-#endif
-  // Double-buffered tiles, ONE barrier per tile: tile it + 1 goes from its staging registers into
-  // the other buffer after tile it's softmax (that buffer was released by the barrier that ended
-  // tile it - 1), tile it + 2 is requested right behind, and the barrier at the end of the iteration
-  // publishes tile it + 1.
-#ifndef T2H_MDBG_NOSTAGE
-  store_kv(0);
-  if (nit > 1) load_kv(1);
-  half_barrier(bar + kh, bar_n += 4, lane);
-#endif
-  for (int it = 0; it < nit; ++it) {
-    const long long tb = TM_NOW();
-    const char* const Ks = Ks0 + (it & 1) * SKV_TILE;
-    const char* const Vs = Ks + SK_TILE;
-
-    // ---- S^T = K Q^T for BOTH 32-key sub-tiles of the tile.  Issue order (l,h)0 (l,h)1 (h,h)0
-    // (h,l)0 (h,l)1 (h,h)1 per k16-step: consecutive matrix instructions never share an
-    // accumulator (a dependent v_mfma waits for its predecessor's last pass).
-    f32x16 st[2], st_lo[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[ks][r] = st_lo[ks][r] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      f16x8 kf[2][2];  // [sub-tile][plane]
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          kf[ks][pl] = *reinterpret_cast<const f16x8*>(Ks + (ks * 32 + l31) * SK_ROW + hh * 16 +
-                                                        (kk >> 1) * T2H_SPLIT_TILE_B + pl * 64 + (kk & 1) * 32);
-#ifdef T2H_MDBG_NOMMA
-      asm volatile("" : "+v"(st[0]), "+v"(st_lo[0]), "+v"(st[1]), "+v"(st_lo[1])
-                   : "v"(kf[0][0]), "v"(kf[0][1]), "v"(kf[1][0]), "v"(kf[1][1]), "v"(qf[kk][0]), "v"(qf[kk][1]));
-#else
-      st_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][1], qf[kk][0], st_lo[0], 0, 0, 0);
-      st_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][1], qf[kk][0], st_lo[1], 0, 0, 0);
-      st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[kk][0], st[0], 0, 0, 0);
-      st_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[kk][1], st_lo[0], 0, 0, 0);
-      st_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][0], qf[kk][1], st_lo[1], 0, 0, 0);
-      st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][0], qf[kk][0], st[1], 0, 0, 0);
-#endif
-    }
-    // ---- online softmax over the tile's 64 keys: this lane's 2 x 16 + the partner half's.  ONE
-    // rescale of the running state per tile, skipped (wave-uniformly) when no lane's maximum moved:
-    // alpha would be exp(0) = 1 exactly, so skipping changes no bit.
-    // Softmax in the base-2 domain: p = exp2(s c - M) with c = log2(e) / sqrt(d) and M the running
-    // maximum of s c (one fma + v_exp_f32 per score; the compensated exp of the exact-fp32 kernel costs
-    // six more instructions per score, and the vector ALU, not the matrix pipe, is what this loop waits
-    // for).  M is the SAME rounded number in every term of a row -- the rescale factor below is formed
-    // from the rounded values too -- so its rounding cancels in the normalisation; what remains is the
-    // rounding of the argument, |arg| ulp on a term of weight 2^arg: below the fp32 summation error.
-    constexpr float SC = 0.125f * 1.44269504088896340736f;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[ks][r] = fmaf(st_lo[ks][r], T2H_SPLIT_LO_INV, st[ks][r]);
-        mx = fmaxf(mx, st[ks][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * SC;
-    const float m_new = fmaxf(m_run, mx);
-    if (__any(m_new > m_run)) {
-      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 0
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          o_acc[dt][r] *= alpha;
-          o_lo[dt][r] *= alpha;
-        }
-      m_run = m_new;
-    }
-#ifndef T2H_MDBG_NOSTAGE
-    if (it + 1 < nit) {
-      store_kv((it + 1) & 1);
-      if (it + 2 < nit) load_kv(it + 2);
-    }
-#endif
-    float psum = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // p = exp(s - m) in place, then O^T += V^T P^T; k16-step j contracts keys
-      // {16j + 4h + (e&3) + 8(e>>2)} = registers 8j..8j+7.  The exp / split VALU work of sub-tile 1
-      // is independent of sub-tile 0's matrix instructions and is scheduled into their shadow.
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#ifdef T2H_MDBG_NOEXP
-        st[ks][r] = fmaf(st[ks][r], SC, -m_run);
-#else
-        st[ks][r] = __builtin_amdgcn_exp2f(fmaf(st[ks][r], SC, -m_run));
-#endif
-        psum += st[ks][r];
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f16x8 pf[2];
-#ifdef T2H_MDBG_NOSPLIT
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf[0][e] = pf[1][e] = (_Float16)st[ks][8 * j + e];
-#else
-        if (j == 0) split8<0>(st[ks], pf[0], pf[1]);
-        else split8<1>(st[ks], pf[0], pf[1]);
-#endif
-        f16x8 vf[2][2];  // [d half][plane]
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            vf[dt][pl] = *reinterpret_cast<const f16x8*>(Vs + (dt * 32 + l31) * SV_ROW + pl * HD * SV_ROW +
-                                                          (ks * 32 + 16 * j + 8 * hh) * 2);
-#ifdef T2H_MDBG_NOMMA
-        asm volatile("" : "+v"(o_acc[0]), "+v"(o_lo[0]), "+v"(o_acc[1]), "+v"(o_lo[1])
-                     : "v"(vf[0][0]), "v"(vf[0][1]), "v"(vf[1][0]), "v"(vf[1][1]), "v"(pf[0]), "v"(pf[1]));
-#else
-        o_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], pf[0], o_lo[0], 0, 0, 0);
-        o_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], pf[0], o_lo[1], 0, 0, 0);
-        o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pf[0], o_acc[0], 0, 0, 0);
-        o_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pf[1], o_lo[0], 0, 0, 0);
-        o_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[1], o_lo[1], 0, 0, 0);
-        o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[0], o_acc[1], 0, 0, 0);
-#endif
-      }
-    }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run += psum;
-    const long long tc = TM_NOW();
-    tm_comp += tc - tb;
-#ifndef T2H_MDBG_NOSTAGE
-    if (it + 1 < nit) half_barrier(bar + kh, bar_n += 4, lane);  // tile it + 1 published, tile it released
-#endif
-    tm_stage += TM_NOW() - tc;
-  }
-
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[dt][r] = fmaf(o_lo[dt][r], T2H_SPLIT_LO_INV, o_acc[dt][r]);
-  // ---- merge the two key halves: waves 4-7 publish (m, l, O), waves 0-3 combine
-  const long long tm2 = TM_NOW();
-  __syncthreads();
-  float* const Ox = smem;                // [4 waves][32 regs][64 lanes]
-  float* const Mx = smem + 4 * 32 * 64;  // borrowed from the staging area below:
-  float* const Lx = Mx + 4 * 64;         // consumed before that area is written
-  if (kh == 1) {
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Ox[(qw * 32 + dt * 16 + r) * 64 + lane] = o_acc[dt][r];
-    Mx[qw * 64 + lane] = m_run;
-    Lx[qw * 64 + lane] = l_run;
-  }
-  __syncthreads();
-  float inv_l = 0.f;
-  if (kh == 0) {
-    const float m2 = Mx[qw * 64 + lane], l2 = Lx[qw * 64 + lane];
-    const float m = fmaxf(m_run, m2);
-    const float a1 = exp2f(m_run - m), a2 = exp2f(m2 - m);  // (maxima are kept in the base-2 domain)
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        o_acc[dt][r] = o_acc[dt][r] * a1 + Ox[(qw * 32 + dt * 16 + r) * 64 + lane] * a2;
-    inv_l = 1.0f / (l_run * a1 + l2 * a2);
-  }
-  __syncthreads();  // Mx/Lx consumed before the staging area is overwritten
-  float* Os = smem + 4 * 32 * 64 + qw * 32 * O_LD;
-  if (kh == 0) {
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        Os[l31 * O_LD + d] = o_acc[dt][r] * inv_l;
-      }
-  }
-  __syncthreads();
-  {  // both key halves store: 16 of the 32 staged rows each
-    const int64_t grow = (int64_t)b * T + q0;
-#pragma unroll
-    for (int it2 = 0; it2 < 2; ++it2) {
-      const int it = it2 + 2 * kh;
-      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-      const f32x4 va = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8);
-      const f32x4 vb = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8 + 4);
-      if (y) {
-        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
-        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
-      }
-      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
-    }
-  }
-#ifdef T2H_MHA_TIMING
-  if (g_mha_timing && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4)) {
-    long long* o = g_mha_timing + (wave == 4 ? 8 : 0);
-    const long long te = clock64();
-    o[0] = te - tm0; o[1] = tm1 - tm0; o[2] = tm_stage; o[3] = tm_comp; o[4] = te - tm2; o[5] = tm2 - tm1;
-  }
-#endif
-}
-
-// the software-pipelined variant (mha_split_pipe_kernel) stages its tiles by LDS-DMA: unpadded images
+// K / Vt tiles are staged by LDS-DMA: unpadded images
 constexpr int DK_TILE = KT * 256;            // K tile: 64 keys x 256 B
 constexpr int DV_TILE = 2 * HD * 128;        // Vt tile: 128 (plane, d) rows x 64 keys x 2 B
 constexpr int DKV_TILE = DK_TILE + DV_TILE;  // per key half and buffer
@@ -679,7 +367,8 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
   // fragment addresses in the swizzled images
   const unsigned xk16 = (unsigned)(hh ^ (l31 & 15)) * 16, xv16 = (unsigned)(hh ^ ((l31 >> 1) & 7)) * 16;
   // S^T = K Q^T for BOTH 32-key sub-tiles of the tile at `Ks`.  Issue order (l,h)0 (l,h)1 (h,h)0
-  // (h,l)0 (h,l)1 (h,h)1 per k16-step: consecutive matrix instructions never share an accumulator.
+  // (h,l)0 (h,l)1 (h,h)1 per k16-step: consecutive matrix instructions never share an accumulator
+  // (a dependent v_mfma waits for its predecessor's last pass).
   auto s_tile = [&](const char* Ks, f32x16 (&st)[2], f32x16 (&st_lo)[2]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -705,9 +394,9 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
 
   int bar_n = 0;
   const long long tm1 = TM_NOW();
-#ifndef T2H_MHA_NOPRIO
-  if (kh == 1) __builtin_amdgcn_s_setprio(1);  // see mha_split_kernel
-#endif
+  // the second-dispatched half of the workgroup loses every issue arbitration against its older SIMD
+  // partner (measured: its loop took 37k cycles against 26k): static priority evens the two out
+  if (kh == 1) __builtin_amdgcn_s_setprio(1);
   // ---- software pipeline over the key tiles (two (K, Vt) buffers per half, one barrier per tile):
   // the matrix pipe forms S^T of tile j + 1 while the vector ALU does the softmax of tile j -- the two
   // are independent, so the compiler interleaves them instead of the wave waiting for its own matrix
@@ -736,7 +425,15 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
     const char* const Vs = Ks0 + buf * DKV_TILE + DK_TILE;
     if (it + 2 < nit) dma_k(it + 2, buf);
     if (it + 1 < nit) dma_v(it + 1, buf ^ 1);
-    // softmax in the base-2 domain (see mha_split_kernel): p = exp2(s c - M)
+    // Online softmax over the tile's 64 keys: this lane's 2 x 16 + the partner half's.  ONE rescale of
+    // the running state per tile, skipped (wave-uniformly) when no lane's maximum moved: alpha would be
+    // exp(0) = 1 exactly, so skipping changes no bit.  Base-2 domain: p = exp2(s c - M) with
+    // c = log2(e) / sqrt(d) and M the running maximum of s c (one fma + v_exp_f32 per score; the
+    // compensated exp of the exact-fp32 kernel costs six more instructions per score, and the vector
+    // ALU, not the matrix pipe, is what this loop waits for).  M is the SAME rounded number in every
+    // term of a row -- the rescale factor below is formed from the rounded values too -- so its
+    // rounding cancels in the normalisation; what remains is the rounding of the argument, |arg| ulp
+    // on a term of weight 2^arg: below the fp32 summation error.
     float mx = -INFINITY;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -896,7 +593,7 @@ extern "C" int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, 
   T2H_REQUIRE(t2h_aligned16(qkv) && t2h_aligned16(y_split), "t2h_mha_noncausal_split_f32: 16-byte alignment");
   const int C = n_head * HD;
   dim3 grid((T / QB) * n_head * B), block(512);
-  int* ovf = t2h_split_overflow_flag_ptr();
+  int* ovf = t2h_split_overflow_flag_ptr(stream);
   T2H_REQUIRE(ovf != nullptr, "t2h_mha_noncausal_split_f32: no overflow flag");
   hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv,
                      static_cast<float*>(nullptr), T, C, n_head, y_split, ovf);
@@ -916,17 +613,10 @@ extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, cons
                   (!y_split || t2h_aligned16(y_split)),
               "t2h_mha_split_f32: 16-byte alignment");
   dim3 grid((T / QB) * n_head * B), block(512);
-  int* ovf = t2h_split_overflow_flag_ptr();
+  int* ovf = t2h_split_overflow_flag_ptr(stream);
   T2H_REQUIRE(ovf != nullptr, "t2h_mha_split_f32: no overflow flag");
-  // T2H_MHA_PIPE=0: the register-staged kernel without the in-wave software pipeline (A/B, tests)
-  const char* const pipe_env = getenv("T2H_MHA_PIPE");
-  const bool pipe = pipe_env ? atoi(pipe_env) != 0 : T2H_MHA_PIPE_DEFAULT;
-  if (pipe)
-    hipLaunchKernelGGL(mha_split_pipe_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt,
-                       y, y_split, T, C, n_head, ovf);
-  else
-    hipLaunchKernelGGL(mha_split_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt, y,
-                       y_split, T, C, n_head, ovf);
+  hipLaunchKernelGGL(mha_split_pipe_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt, y,
+                     y_split, T, C, n_head, ovf);
   T2H_CHECK_LAUNCH("t2h_mha_split_f32");
   return T2H_OK;
 }

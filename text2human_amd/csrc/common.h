@@ -13,9 +13,11 @@ void t2h_set_error(const char* fmt, ...);
 
 // Device-resident sticky flag of the split-precision producers (api.hip): set when a value
 // that is about to be written as split rows does not fit fp16's range (|x| >= 65504 would
-// turn into inf / NaN planes).  Read back by t2h_split_overflow().  One int per device,
-// allocated on first use; NULL only if that allocation failed (reported by the caller).
-int* t2h_split_overflow_flag_ptr();
+// turn into inf / NaN planes).  Read back by t2h_split_overflow().  One word per (device,
+// stream), allocated the first time a stream is seen, so that two models driven on two
+// streams neither share nor clear each other's flag; NULL only if that allocation failed
+// (reported by the caller).
+int* t2h_split_overflow_flag_ptr(void* stream);
 
 #define T2H_REQUIRE(cond, ...)                 \
   do {                                         \

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(CS_NT, 2) void conv_split_kernel(const t2h_gemm_arg
   }
 }
 
-int g_force_bm = 0;
+thread_local int g_force_bm = 0;  // tuning / test hook of the calling thread
 
 }  // namespace
 

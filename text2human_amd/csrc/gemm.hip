@@ -561,7 +561,7 @@ int launch_by_cfg(int cfg, const t2h_gemm_args& a, hipStream_t s) {
   }
 }
 
-int g_force_cfg = -1;  // experiments / autotuning: t2h_gemm_force_config()
+thread_local int g_force_cfg = -1;  // experiments / autotuning of the calling thread: t2h_gemm_force_config()
 
 // Tile choice.  256 CUs, <= 2 resident 4-wave workgroups per CU (LDS).
 int pick_cfg(const t2h_gemm_args& a) {

@@ -172,7 +172,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   constexpr int SMEM_B = MAIN_B > EPI_B ? MAIN_B : EPI_B;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
-  __shared__ __attribute__((aligned(16))) float ln_tab[2 * BM];  // folded LayerNorm: [mean | rstd] of the tile's rows
 
   G1_MARK(0);
   const int kg = KS == 1 ? 0 : (int)threadIdx.x / NT;  // K group
@@ -192,58 +191,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     m0 = mt * BM;
     n0 = (lin - mt * nbx) * BN;
   }
-  // folded LayerNorm, consumer side: (mean, rstd) of this tile's A rows from their 32-column partials
-  // (mean_i, M2_i), combined in fixed order (Chan et al.): mean = avg mean_i, M2 = sum M2_i +
-  // 32 sum (mean_i - mean)^2.  Called once the first K tiles have been requested, so that the partials
-  // travel beside them; the table is read in the epilogue, many barriers later.
-  auto ln_prologue = [&] {
-    if (p.ln_part_in == nullptr) return;
-    const int np2 = p.K / 64;  // pairs of partials = 16-byte pieces per row (host: K % 64 == 0)
-    for (int r = threadIdx.x; r < BM; r += 64 * WARPS_M * WARPS_N * KS) {
-      const f32x4* pp = reinterpret_cast<const f32x4*>(p.ln_part_in) + (int64_t)min(m0 + r, p.M - 1) * np2;
-      float ms = 0.f, m2 = 0.f, dev = 0.f, mean;
-      if (np2 <= 8) {  // K <= 512: the row's partials in flight together, kept in registers
-        f32x4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i < np2) v[i] = pp[i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i < np2) {
-            ms += v[i][0];
-            ms += v[i][2];
-            m2 += v[i][1];
-            m2 += v[i][3];
-          }
-        mean = ms / (float)(2 * np2);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i < np2) {
-            const float d0 = v[i][0] - mean, d1 = v[i][2] - mean;
-            dev = fmaf(d0, d0, dev);
-            dev = fmaf(d1, d1, dev);
-          }
-      } else {  // same sums in the same order, second pass re-reads (cache hits)
-        for (int i = 0; i < np2; ++i) {
-          const f32x4 v = pp[i];
-          ms += v[0];
-          ms += v[2];
-          m2 += v[1];
-          m2 += v[3];
-        }
-        mean = ms / (float)(2 * np2);
-        for (int i = 0; i < np2; ++i) {
-          const f32x4 v = pp[i];
-          const float d0 = v[0] - mean, d1 = v[2] - mean;
-          dev = fmaf(d0, d0, dev);
-          dev = fmaf(d1, d1, dev);
-        }
-      }
-      const float var = fmaf(32.f, dev, m2) / (float)p.K;
-      ln_tab[r] = mean;
-      ln_tab[BM + r] = 1.0f / sqrtf(var + p.ln_eps);
-    }
-  };
   const int nk = p.K / (32 * KS);  // K tiles per group (host guarantees K % (32 KS) == 0)
   const int last = nk - 1;
   const int64_t row_b = (int64_t)nk * (SP_TILE_B * KS);  // bytes per split row
@@ -339,7 +286,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     constexpr int PC[3] = {1, 1, 0};
     dma(0, 0);
     dma(1, TILE_IMG_B);
-    ln_prologue();
     wait_landed();  // tile 0
     pp_barrier();
     G1_MARK(1);
@@ -444,7 +390,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   // tile 0 is complete once at most the L younger loads of tile 1 are outstanding
   issue(set0{}, 0);
   issue(set1{}, 1);
-  ln_prologue();
 #pragma unroll
   for (int i = 0; i < L; ++i) {
     wait_vmcnt16<L>(rg[0][i]);
@@ -540,7 +485,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   float* const Og = Ot + kg * (NWG * OW);                        // this group's
   // value of accumulator register r of MFMA tile (ti, tj) as it is staged: both partial
   // accumulators folded together, plus the bias (K group 0 only)
-  const bool ln_in = p.ln_part_in != nullptr;
   auto fin = [&](int ti, int tj, int r, float bv) {
     return fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]) + bv;
   };
@@ -556,7 +500,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #pragma unroll
       for (int tj = 0; tj < TN; ++tj) {
         const int col = n0 + wn0 + tj * 32 + l31;
-        const float bv = (p.bias && col < p.N && kg == 0 && !ln_in) ? p.bias[col] : 0.f;
+        const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           f32x4 w4;
@@ -586,18 +530,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
         va += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + cl * OT_LD + ra);
         vb += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + cl * OT_LD + ra + 8);
       }
-      if (ln_in) {  // rows wm0 + ra .. + 3 and + 8 .. + 11 of the tile, one column
-        const float cs = p.ln_colsum[col], bb = p.bias ? p.bias[col] : 0.f;
-        const f32x4 ma = *reinterpret_cast<const f32x4*>(ln_tab + wm0 + ra);
-        const f32x4 mb = *reinterpret_cast<const f32x4*>(ln_tab + wm0 + ra + 8);
-        const f32x4 ra4 = *reinterpret_cast<const f32x4*>(ln_tab + BM + wm0 + ra);
-        const f32x4 rb4 = *reinterpret_cast<const f32x4*>(ln_tab + BM + wm0 + ra + 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          va[e] = fmaf(ra4[e], fmaf(-ma[e], cs, va[e]), bb);
-          vb[e] = fmaf(rb4[e], fmaf(-mb[e], cs, vb[e]), bb);
-        }
-      }
       t2h_split_guard8(ovf, va, vb);
       t2h_f16x8 vh, vl;
 #pragma unroll
@@ -622,7 +554,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) {
       const int col = n0 + wn0 + tj * 32 + l31;
-      const float bv = (p.bias && col < p.N && kg == 0 && !ln_in) ? p.bias[col] : 0.f;
+      const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = fin(ti, tj, r, bv);
@@ -632,21 +564,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   constexpr int CPR = WN / 8;              // 8-column chunks per staged row
   constexpr int NCH = WM * CPR / 64 / KS;  // chunks per lane (the K groups share the stores)
   static_assert(NCH >= 1 && NCH * 64 * KS == WM * CPR, "epilogue chunking");
-  // a lane's chunks all sit in the same 8 columns (64 % CPR == 0): the folded-LayerNorm column
-  // vectors are loaded once, not per chunk
-  static_assert(64 % CPR == 0, "a lane keeps its columns across chunks");
-  f32x4 ln_ca = {0.f, 0.f, 0.f, 0.f}, ln_cb = ln_ca, ln_ba = ln_ca, ln_bb = ln_ca;
-  if (ln_in) {
-    const int col = n0 + wn0 + (lane % CPR) * 8;
-    if (col < p.N) {
-      ln_ca = *reinterpret_cast<const f32x4*>(p.ln_colsum + col);
-      ln_cb = *reinterpret_cast<const f32x4*>(p.ln_colsum + col + 4);
-      if (p.bias) {
-        ln_ba = *reinterpret_cast<const f32x4*>(p.bias + col);
-        ln_bb = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
-      }
-    }
-  }
 #pragma unroll
   for (int it = 0; it < NCH; ++it) {
     const int c = lane + 64 * (it + kg * NCH);
@@ -659,14 +576,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     if (KS == 2) {
       va += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + rl * O_LD + c8);
       vb += *reinterpret_cast<const f32x4*>(Ot + NWG * OW + rl * O_LD + c8 + 4);
-    }
-    if (ln_in) {
-      const float mean = ln_tab[wm0 + rl], rstd = ln_tab[BM + wm0 + rl];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        va[e] = fmaf(rstd, fmaf(-mean, ln_ca[e], va[e]), ln_ba[e]);
-        vb[e] = fmaf(rstd, fmaf(-mean, ln_cb[e], vb[e]), ln_bb[e]);
-      }
     }
     if (p.epi_act == 1) {
       va = gelu_erf_v(va);
@@ -687,25 +596,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col + 4) = vb;
     }
     if (p.C_split) t2h_store_split8(p.C_split, row, p.N, col, va, vb, ovf);
-    if (p.ln_part_out) {
-      // (mean, M2) of this row's 32-column slice: the 4 neighbouring lanes hold its 4 chunks (CPR is
-      // a multiple of 4 and N of 32, so the group is valid or skipped as one)
-      float su = ((va[0] + va[1]) + (va[2] + va[3])) + ((vb[0] + vb[1]) + (vb[2] + vb[3]));
-      su += __shfl_xor(su, 1, 64);
-      su += __shfl_xor(su, 2, 64);
-      const float mu = su * (1.0f / 32.0f);
-      float q = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float da = va[e] - mu, db = vb[e] - mu;
-        q = fmaf(da, da, q);
-        q = fmaf(db, db, q);
-      }
-      q += __shfl_xor(q, 1, 64);
-      q += __shfl_xor(q, 2, 64);
-      if ((c & 3) == 0)
-        reinterpret_cast<float2*>(p.ln_part_out)[(int64_t)row * (p.N / 32) + (col >> 5)] = make_float2(mu, q);
-    }
   }
 #ifdef T2H_GEMM_TIMING
   G1_MARK(3);
@@ -781,7 +671,7 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE((int64_t)(a.M > a.N ? a.M : a.N) * a.K * 4 < (int64_t(1) << 31),
               "t2h_gemm_split_f32: operands are addressed with 32-bit byte offsets (each must span < 2 GiB)");
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
-  int* ovf = t2h_split_overflow_flag_ptr();
+  int* ovf = t2h_split_overflow_flag_ptr(s);
   T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
   hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP>), grid,
                      dim3(64 * WARPS_M * WARPS_N * KS), 0, s, a, ovf);
@@ -789,12 +679,7 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   return T2H_OK;
 }
 
-int g_force_split_cfg = -1;
-
-bool pp_default() {
-  static const bool on = !(getenv("T2H_GEMM_SPLIT_PP") && atoi(getenv("T2H_GEMM_SPLIT_PP")) == 0);
-  return on;
-}
+thread_local int g_force_split_cfg = -1;  // tuning / test hook of the calling thread
 
 }  // namespace
 
@@ -826,13 +711,6 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
                     a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,
                 "t2h_gemm_split_f32: bad Vt routing (col0=%d T=%d hd=%d M=%d N=%d)", a.vt_col0, a.vt_T, a.vt_hd,
                 a.M, a.N);
-  if (a.ln_part_out)
-    T2H_REQUIRE(a.N % 32 == 0 && a.Vt == nullptr, "t2h_gemm_split_f32: ln_part_out needs N %% 32 == 0 and no Vt routing");
-  if (a.ln_part_in)
-    T2H_REQUIRE(a.ln_colsum != nullptr && a.N % 8 == 0 && a.K % 64 == 0 && t2h_aligned16(a.ln_colsum) &&
-                    t2h_aligned16(a.ln_part_in) && (a.bias == nullptr || t2h_aligned16(a.bias)),
-                "t2h_gemm_split_f32: ln_part_in needs ln_colsum, N %% 8 == 0, K %% 64 == 0 and 16-byte "
-                "aligned vectors");
   hipStream_t s = static_cast<hipStream_t>(stream);
   int cfg = g_force_split_cfg;
   if (cfg < 0) {
@@ -848,19 +726,18 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     else if (tiles_big >= 192)
       // 256x128 tiles wherever they give (nearly) every CU one: q|k|v / fc1 at M = 4096 (192 / 256
       // tiles) and every sampler Linear but proj at M = 16384 (q|k|v 99 vs 104 / 126 us for the 128x64 /
-      // 128x128 tiles, fc2 93 vs 111).  The ping-pong LDS-DMA loop (8) is 5-6 % faster than the
-      // register-staged one (4; T2H_GEMM_SPLIT_PP=0 for the A/B)
-      cfg = pp_default() ? 8 : 4;
+      // 128x128 tiles, fc2 93 vs 111), on the ping-pong LDS-DMA loop (5-6 % faster than the same tile
+      // on the register-staged loop, the twin round 2 kept for the A/B and round 3 removed)
+      cfg = 8;
     else if (tiles128 >= 1024) cfg = 1;
     else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
     else cfg = 0;
   }
-  const bool skinny_ok = a.N % 16 == 0 && !a.Vt && !a.ln_part_out && !a.ln_part_in &&
-                         (a.bias == nullptr || t2h_aligned16(a.bias));
+  const bool skinny_ok = a.N % 16 == 0 && !a.Vt && (a.bias == nullptr || t2h_aligned16(a.bias));
   if (g_force_split_cfg < 0 && a.M <= 64 && skinny_ok) cfg = 9;
   if (cfg == 9) {
-    T2H_REQUIRE(skinny_ok, "t2h_gemm_split_f32: the few-rows kernel needs N %% 16 == 0 and no Vt / LayerNorm routing");
-    int* ovf = t2h_split_overflow_flag_ptr();
+    T2H_REQUIRE(skinny_ok, "t2h_gemm_split_f32: the few-rows kernel needs N %% 16 == 0 and no Vt routing");
+    int* ovf = t2h_split_overflow_flag_ptr(s);
     T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
     hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), 0, s, a, ovf);
     T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
@@ -870,7 +747,6 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64
     case 2: return launch_split<64, 64, 2, 2>(a, s);    // 4 waves, wave tile 32x32
     case 3: return launch_split<128, 64, 4, 2>(a, s);   // 8 waves, wave tile 32x32
-    case 4: return launch_split<256, 128, 4, 2>(a, s);  // 8 waves, wave tile 64x64
     case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
     case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
     case 8: return launch_split<256, 128, 4, 2, 1, 2>(a, s);  // 8 waves, wave tile 64x64, ping-pong LDS-DMA loop
@@ -881,7 +757,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
 extern "C" int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream) {
   T2H_REQUIRE(x && out && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0, "t2h_split_rows_f32: bad arguments");
   const int64_t total = rows * (C / 4);
-  int* ovf = t2h_split_overflow_flag_ptr();
+  int* ovf = t2h_split_overflow_flag_ptr(stream);
   T2H_REQUIRE(ovf != nullptr, "t2h_split_rows_f32: no overflow flag");
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ldx, out, total, C, ovf);

@@ -273,7 +273,7 @@ extern "C" int t2h_layernorm_split_f32(const float* x, const float* gamma, const
   dim3 grid((rows + T2H_LN_RPB - 1) / T2H_LN_RPB), block(64 * T2H_LN_RPB);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* y = reinterpret_cast<float*>(y_split);
-  int* ovf = t2h_split_overflow_flag_ptr();
+  int* ovf = t2h_split_overflow_flag_ptr(stream);
   T2H_REQUIRE(ovf != nullptr, "t2h_layernorm_split_f32: no overflow flag");
   if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
   else if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
@@ -352,7 +352,7 @@ extern "C" int t2h_gn_apply_split_f32(const float* x, int32_t ldx, const float* 
   if (scale)
     T2H_REQUIRE(rows_per_img > 0 && tbl_ld % 4 == 0 && t2h_aligned16(scale) && t2h_aligned16(shift),
                 "t2h_gn_apply_split_f32: tables");
-  int* ovf = t2h_split_overflow_flag_ptr();
+  int* ovf = t2h_split_overflow_flag_ptr(stream);
   T2H_REQUIRE(ovf != nullptr, "t2h_gn_apply_split_f32: no overflow flag");
   const int64_t total = rows * (C / 8);
   hipLaunchKernelGGL(gn_apply_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

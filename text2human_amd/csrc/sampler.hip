@@ -334,6 +334,71 @@ __global__ void philox_exponential_kernel(uint64_t seed, uint64_t offset, uint32
   if (e < numel) out[e] = torch_exponential_at(seed, offset, grid_threads, (uint64_t)e);
 }
 
+// ---- torch's `rand` draw, element by element: the same engine / element <-> (thread, counter)
+// mapping as above (distribution_elementwise_grid_stride_kernel, unroll 4) with ATen's uniform
+// transform (uniform_kernel of ATen/native/cuda/DistributionTemplates.h, from = 0, to = 1):
+// value = u * 1 + 0 with u = curand_uniform in (0, 1], and the bounds reversed: value == 1 -> 0.
+__device__ __forceinline__ float torch_uniform_at(uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t e) {
+  const uint64_t idx = e % grid_threads, m = e / grid_threads;
+  const uint64_t ctr = offset / 4 + (m >> 2);
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)idx, (uint32_t)(idx >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const uint32_t v = c[m & 3];
+  const float u = __builtin_fmaf((float)v, 2.3283064365386963e-10f, 2.3283064365386963e-10f);  // (0, 1]
+  return u == 1.0f ? 0.0f : u;
+}
+
+__global__ void philox_uniform_kernel(uint64_t seed, uint64_t offset, uint32_t grid_threads, float* __restrict__ out,
+                                      int64_t numel) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < numel) out[e] = torch_uniform_at(seed, offset, grid_threads, (uint64_t)e);
+}
+
+// ---- the WHOLE unmasking schedule of a sampling run in one launch.  Which token is unmasked at
+// which step (models/sample_model.py:286-292) depends on the `rand` draws and on nothing the
+// transformer computes; the generator offset of every draw depends on the schedule only through
+// the number of heads that sample at a step (one full exponential_ draw per ACTIVE head, :301-306).
+// So the `rand` draws are reproduced here, step after step, each at the offset the reference's
+// generator would hold: off(t-1) = off(t) + rand_inc + popcount(active heads at t) * expo_inc.
+// One workgroup (the steps are sequential and a step is n / 1024 Philox blocks per thread);
+// outputs: step_of_row[i] = the step at which token row i changes (every row changes exactly once:
+// at t = 1 the threshold is 1), head_mask[t] = bit h set iff head h samples at step t.
+constexpr int SCHED_THREADS = 1024, SCHED_MAX_STEPS = 4096;
+__global__ __launch_bounds__(SCHED_THREADS) void unmask_schedule_kernel(
+    uint64_t seed, uint64_t offset, uint32_t rand_grid_threads, uint32_t rand_inc, uint32_t expo_inc,
+    const int64_t* __restrict__ tex, int n, int steps, int32_t* __restrict__ step_of_row,
+    uint32_t* __restrict__ head_mask) {
+  __shared__ uint32_t mask_s[SCHED_MAX_STEPS + 1];  // one word per step: no reset, one barrier per step
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int e = tid; e < n; e += SCHED_THREADS) step_of_row[e] = 0;
+  for (int t = tid; t <= steps; t += SCHED_THREADS) mask_s[t] = 0;
+  __syncthreads();
+  uint64_t off = offset;
+  for (int t = steps; t >= 1; --t) {
+    const float thresh = 1.0f / (float)t;  // `1 / t.float()`: an fp32 reciprocal
+    uint32_t m = 0;
+    for (int e = tid; e < n; e += SCHED_THREADS) {
+      if (step_of_row[e] != 0) continue;  // already unmasked (written by this same thread)
+      if (torch_uniform_at(seed, off, rand_grid_threads, (uint64_t)e) < thresh) {
+        step_of_row[e] = t;
+        m |= 1u << (int)tex[e];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+    if (lane == 0 && m) atomicOr(&mask_s[t], m);
+    __syncthreads();
+    off += (uint64_t)rand_inc + (uint64_t)__popc(mask_s[t]) * expo_inc;
+  }
+  for (int t = tid; t <= steps; t += SCHED_THREADS) head_mask[t] = mask_s[t];
+}
+
 // ---- two-launch form of the same tail (t2h_sample_heads with a logits workspace).  One workgroup
 // per changed row streams 2 MB of head weights by itself (~50 us per step with ~16 rows on 16 CUs);
 // here SL_SPLIT workgroups per row take n_class / SL_SPLIT classes each (LN_f recomputed per
@@ -417,12 +482,17 @@ __global__ __launch_bounds__(SH_THREADS) void sample_pick_kernel(const t2h_sampl
   mx = red[0];
 #pragma unroll
   for (int k = 1; k < NW; ++k) mx = fmaxf(mx, red[k]);
-  const float* er = a.philox_grid_threads ? nullptr : a.expo[head] + (int64_t)row * a.n_class;
+  // noise of this row: explicit compact rows (expo_rows[expo_slot[slot]]), the head's explicit full
+  // tensor, or computed -- at the row's own generator offset when the list mixes steps
+  const float* er = a.expo_rows ? a.expo_rows + (int64_t)(a.expo_slot ? a.expo_slot[slot] : slot) * a.n_class
+                    : a.philox_grid_threads ? nullptr
+                                            : a.expo[head] + (int64_t)row * a.n_class;
+  const uint64_t poff = a.row_philox_offset ? a.row_philox_offset[slot] : a.philox_offset[head];
   float best = -1.f;
   int best_j = 0x7fffffff;
   for (int j = tid; j < a.n_class; j += SH_THREADS) {
     const float q = er ? er[j]
-                       : torch_exponential_at(a.philox_seed, a.philox_offset[head], a.philox_grid_threads,
+                       : torch_exponential_at(a.philox_seed, poff, a.philox_grid_threads,
                                               (uint64_t)row * a.n_class + j);
     const float sc = expf(lg[j] - mx) / q;
     if (sc > best) {
@@ -528,6 +598,10 @@ extern "C" int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream)
   T2H_REQUIRE(!a.hidden_compact || a.logits_ws != nullptr, "t2h_sample_heads: compact hidden needs the two-launch form");
   T2H_REQUIRE(a.philox_grid_threads == 0 || a.logits_ws != nullptr,
               "t2h_sample_heads: the in-kernel exponential_ draw needs the two-launch form (logits_ws)");
+  T2H_REQUIRE((a.row_philox_offset == nullptr || a.philox_grid_threads != 0) &&
+                  ((a.expo_rows == nullptr && a.row_philox_offset == nullptr) || a.logits_ws != nullptr),
+              "t2h_sample_heads: per-row noise (row_philox_offset / expo_rows) needs the two-launch form and, for "
+              "offsets, philox_grid_threads");
   if (a.n_rows == 0) return T2H_OK;
   if (a.logits_ws) {  // two launches, SL_SPLIT workgroups per row stream the head weights
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -568,6 +642,28 @@ extern "C" int t2h_masked_ce_heads(const float* hidden, const float* lnf_gamma, 
                      w_heads, tex, mask, gt_lists, ce_rows, B * T, n_class, n_heads);
   hipLaunchKernelGGL(segment_sum_kernel, dim3(B), dim3(256), 0, s, ce_rows, ce_samples, T);
   T2H_CHECK_LAUNCH("t2h_masked_ce_heads");
+  return T2H_OK;
+}
+
+extern "C" int t2h_philox_uniform_f32(uint64_t seed, uint64_t offset, uint32_t grid_threads, float* out,
+                                      int64_t numel, void* stream) {
+  T2H_REQUIRE(out && numel > 0 && grid_threads > 0 && offset % 4 == 0, "t2h_philox_uniform_f32: bad arguments");
+  hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), seed, offset, grid_threads, out, numel);
+  T2H_CHECK_LAUNCH("t2h_philox_uniform_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_unmask_schedule(uint64_t seed, uint64_t offset, uint32_t rand_grid_threads, uint32_t rand_inc,
+                                   uint32_t expo_inc, const int64_t* tex, int32_t n, int32_t steps, int32_t n_heads,
+                                   int32_t* step_of_row, uint32_t* head_mask, void* stream) {
+  T2H_REQUIRE(tex && step_of_row && head_mask, "t2h_unmask_schedule: NULL pointer");
+  T2H_REQUIRE(n > 0 && steps >= 1 && steps <= SCHED_MAX_STEPS && n_heads > 0 && n_heads <= T2H_MAX_HEADS &&
+                  rand_grid_threads > 0 && offset % 4 == 0 && rand_inc % 4 == 0 && expo_inc % 4 == 0,
+              "t2h_unmask_schedule: bad arguments (n=%d steps=%d n_heads=%d)", n, steps, n_heads);
+  hipLaunchKernelGGL(unmask_schedule_kernel, dim3(1), dim3(SCHED_THREADS), 0, static_cast<hipStream_t>(stream), seed,
+                     offset, rand_grid_threads, rand_inc, expo_inc, tex, n, steps, step_of_row, head_mask);
+  T2H_CHECK_LAUNCH("t2h_unmask_schedule");
   return T2H_OK;
 }
 

@@ -9,9 +9,10 @@ HBM.  PyTorch only allocates tensors and provides the stream.
 """
 import os
 
+import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, schedule
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU, PRO_NONE, PRO_SWISH
 
 
@@ -138,7 +139,7 @@ class VQGANStack:
                                residual=res)
                 h, w = 2 * h, 2 * w
             elif lv['level'] == 4 and bot_h is not None:
-                t = t + bot_h
+                raise _lib.T2HError('decoder level 4 has no Upsample conv to carry bot_h (vqgan_arch.py:1021-1024)')
         return self._norm_conv3x3(t, f'{nm}.norm_out', f'{nm}.conv_out', n_img, h, w), h, w
 
     def decode_res(self, z, n_img, h, w, upscale=False):
@@ -158,45 +159,39 @@ class SamplerNet:
     tail kernel.  24 x [LN, QKV GEMM, flash MHA, proj GEMM(+res), LN, fc1
     GEMM(+GELU), fc2 GEMM(+res)]."""
 
-    def __init__(self, P, desc, n_head, name='tf', split=False, split_mha=True, n_streams=1):
+    def __init__(self, P, desc, n_head, name='tf', split=False, split_mha=True):
         self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
         self.split = split
-        # n_streams > 1 (split path): the batch is cut into that many independent slices
-        # whose 24-layer kernel chains run on separate HIP streams, so one slice's launch
-        # latency / first-tile fill / epilogue tail overlaps the other's main loops
-        self.n_streams = n_streams
-        self._streams = None
         self._deferred = None
         # split_mha (with split): attention on the fp16 matrix cores too -- the q|k|v
         # projection writes q, k as split rows and v as transposed planes, no fp32 qkv
         self.split_mha = split_mha
-        # fold_ln (T2H_FOLD_LN=1, with split + split_mha; off by default): no LayerNorm launches inside the
-        # stack.  proj / fc2 (the writers of the residual stream) also emit split(x) and per-row partial
-        # moments; q|k|v / fc1 run on split(x) with gamma folded into their weights and apply (mean, rstd)
-        # in the epilogue (t2h_gemm_split_args.ln_part_*).  Layer 0's ln1 (input from the embedding) stays
-        # a kernel.  Measured at B=8: the 46 LayerNorm launches it removes per step (5.1 us each) are paid
-        # back almost entirely by the four GEMMs (+1.5 .. +5 us each): 816 vs 818-826 ms per batch.
-        self.fold_ln = (split and split_mha and os.environ.get('T2H_FOLD_LN', '0') == '1'
-                        and f'{name}.0.fc1.wf_split' in P)
         self._buf = {}
+        self.last_stats = None  # schedule.stats of the last sample_tokens run
 
     def _buffers(self, M, C, dev):
         key = (M, C, str(dev))
         if key not in self._buf:
             e = lambda n: torch.empty((M, n), device=dev, dtype=torch.float32)
+            R = self.TRIM_MAX_ROWS
             self._buf = {key: dict(x=e(C), h=e(C), qkv=e(3 * C), y=e(C), u=e(4 * C),
                                    h_split=ops.split_rows_empty(M, C, dev), y_split=ops.split_rows_empty(M, C, dev),
                                    u_split=ops.split_rows_empty(M, 4 * C, dev),
                                    qk_split=ops.split_rows_empty(M, 3 * C, dev),
-                                   x_split=ops.split_rows_empty(M, C, dev), ln_part=ops.ln_partials_empty(M, C, dev),
-                                   vt=ops.vt_empty(M // 512 if M % 512 == 0 else 1, self.n_head, 512, dev))}
+                                   vt=ops.vt_empty(M // 512 if M % 512 == 0 else 1, self.n_head, 512, dev),
+                                   # the last layer's tail on the changed rows (finish_tail)
+                                   xc=torch.empty((R, C), device=dev, dtype=torch.float32),
+                                   yc=ops.split_rows_empty(R, C, dev), hc=ops.split_rows_empty(R, C, dev),
+                                   uc=ops.split_rows_empty(R, 4 * C, dev))}
         return self._buf[key]
 
     # The LAST layer's row-wise tail (proj + residual, LayerNorm, fc1 + GELU, fc2 + residual) only
-    # matters for the rows whose logits are sampled this step -- ~16 of 4096 at B=8.  With
+    # matters for the rows whose logits are sampled this round -- ~16 of 4096 at B=8.  With
     # defer_tail=True, hidden() stops after the last layer's attention; finish_tail() evaluates the
-    # tail on the compacted changed rows once the host knows how many there are (the Linears, the
-    # LayerNorm and the residual adds are row-wise, so those rows come out as in the full evaluation).
+    # tail on the compacted changed rows.  The Linears, the LayerNorm and the residual adds are
+    # row-wise, so those rows equal the full evaluation's up to the summation order of the few-rows
+    # GEMM kernel (K split over 8 waves): tolerance-level equality, not bitwise
+    # (tests/test_gpu_edge_cases.py compares the tokens of both forms on the bench configuration).
     TRIM_MAX_ROWS = 256
 
     def hidden(self, idx, segm_tok, tex_tok, defer_tail=False):
@@ -207,85 +202,39 @@ class SamplerNet:
         x, h, qkv, y, u = buf['x'], buf['h'], buf['qkv'], buf['y'], buf['u']
         ops.embed_sum4(idx, segm_tok, tex_tok, P[f'{nm}.tok_emb'], P[f'{nm}.pos_emb'],
                        P[f'{nm}.segm_emb'], P[f'{nm}.tex_emb'], out=x)
+        L = self.desc['n_layers']
+        self._deferred = None
         if self.split:
             # Split-precision path: the four Linears run on the fp16 matrix cores with
             # 2 x fp16 planes per operand (fp32-class accuracy, gemm_split.hip).  The
             # producers write split rows directly: LayerNorm -> h, attention -> y,
-            # fc1's GELU epilogue -> u; the residual stream x and q|k|v stay fp32.
+            # fc1's GELU epilogue -> u; the residual stream x stays fp32.
             M = B * T
-            hs, ys, us = buf['h_split'], buf['y_split'], buf['u_split']
+            hs, ys, us, qks = buf['h_split'], buf['y_split'], buf['u_split'], buf['qk_split']
             vt = buf['vt']
-            if self.split_mha and tuple(vt.shape) != (B, self.n_head, 3, C // self.n_head, T):
-                vt = buf['vt'] = ops.vt_empty(B, self.n_head, T, idx.device, C // self.n_head)
-            qks = buf['qk_split']
-            ns = self.n_streams if (self.split_mha and B % max(self.n_streams, 1) == 0) else 1
-            # batch slices: (rows lo:hi, batch size); all buffers are row-major over B*T rows
-            Bs = B // ns
-            sl = [(j * Bs * T, (j + 1) * Bs * T, j * Bs, (j + 1) * Bs) for j in range(ns)]
-
-            fold = self.fold_ln and ns == 1
-            xsp, part = buf['x_split'], buf['ln_part']
-            L = self.desc['n_layers']
-
-            def layer(i, lo, hi, b0, b1, tail=True):
+            hd = C // self.n_head
+            if self.split_mha and tuple(vt.shape) != (B, self.n_head, 2, hd, T):
+                vt = buf['vt'] = ops.vt_empty(B, self.n_head, T, idx.device, hd)
+            for i in range(L):
                 p = f'{nm}.{i}'
-                m, xs = hi - lo, x[lo:hi]
-                if fold and i > 0:  # split(x) and its row moments came with the previous layer's fc2
-                    ops.gemm_split(xsp, P[f'{p}.qkv.wf_split'], m, 3 * C, C, out_split=qks, bias=P[f'{p}.qkv.bf'],
-                                   vt=vt, vt_col0=2 * C, vt_T=T, vt_hd=C // self.n_head,
-                                   ln_in=(part, P[f'{p}.qkv.cs']))
+                ops.layernorm_split(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs)
+                if self.split_mha:
+                    ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out_split=qks, bias=P[f'{p}.qkv.b'],
+                                   vt=vt, vt_col0=2 * C, vt_T=T, vt_hd=hd)
                     ops.mha_split(qks, 3 * C, vt, B, T, self.n_head, out_split=ys)
                 else:
-                    ops.layernorm_split(xs, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs[lo:hi])
-                    if self.split_mha:
-                        ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out_split=qks[lo:hi],
-                                       bias=P[f'{p}.qkv.b'], vt=vt[b0:b1], vt_col0=2 * C, vt_T=T,
-                                       vt_hd=C // self.n_head)
-                        ops.mha_split(qks[lo:hi], 3 * C, vt[b0:b1], b1 - b0, T, self.n_head, out_split=ys[lo:hi])
-                    else:
-                        ops.gemm_split(hs[lo:hi], P[f'{p}.qkv.w_split'], m, 3 * C, C, out=qkv[lo:hi],
-                                       bias=P[f'{p}.qkv.b'])
-                        ops.mha_noncausal_split(qkv[lo:hi], b1 - b0, T, self.n_head, ys[lo:hi])
-                if not tail:
-                    return
-                if fold:
-                    ops.gemm_split(ys, P[f'{p}.proj.w_split'], m, C, C, out=x, bias=P[f'{p}.proj.b'], residual=x,
-                                   out_split=xsp, ln_part_out=part)
-                    ops.gemm_split(xsp, P[f'{p}.fc1.wf_split'], m, 4 * C, C, out_split=us, bias=P[f'{p}.fc1.bf'],
-                                   act=ACT_GELU, ln_in=(part, P[f'{p}.fc1.cs']))
-                    nxt = i + 1 < L  # the last layer's output only feeds ln_f in the sampling tail
-                    ops.gemm_split(us, P[f'{p}.fc2.w_split'], m, C, 4 * C, out=x, bias=P[f'{p}.fc2.b'], residual=x,
-                                   out_split=xsp if nxt else None, ln_part_out=part if nxt else None)
-                    return
-                ops.gemm_split(ys[lo:hi], P[f'{p}.proj.w_split'], m, C, C, out=xs, bias=P[f'{p}.proj.b'],
-                               residual=xs)
-                ops.layernorm_split(xs, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs[lo:hi])
-                ops.gemm_split(hs[lo:hi], P[f'{p}.fc1.w_split'], m, 4 * C, C, out_split=us[lo:hi],
-                               bias=P[f'{p}.fc1.b'], act=ACT_GELU)
-                ops.gemm_split(us[lo:hi], P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xs, bias=P[f'{p}.fc2.b'],
-                               residual=xs)
-
-            self._deferred = None
-            if ns == 1:
-                for i in range(L - 1):
-                    layer(i, *sl[0])
-                layer(L - 1, *sl[0], tail=not defer_tail)
-                if defer_tail:
+                    ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out=qkv, bias=P[f'{p}.qkv.b'])
+                    ops.mha_noncausal_split(qkv, B, T, self.n_head, ys)
+                if i == L - 1 and defer_tail:
                     self._deferred = (x, ys, M, C)
-                return x
-            if self._streams is None or len(self._streams) != ns:
-                self._streams = [torch.cuda.Stream(device=idx.device) for _ in range(ns)]
-            main = torch.cuda.current_stream()
-            for st in self._streams:
-                st.wait_stream(main)
-            for i in range(self.desc['n_layers']):
-                for j, st in enumerate(self._streams):
-                    with torch.cuda.stream(st):
-                        layer(i, *sl[j])
-            for st in self._streams:
-                main.wait_stream(st)
+                    return x
+                ops.gemm_split(ys, P[f'{p}.proj.w_split'], M, C, C, out=x, bias=P[f'{p}.proj.b'], residual=x)
+                ops.layernorm_split(x, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs)
+                ops.gemm_split(hs, P[f'{p}.fc1.w_split'], M, 4 * C, C, out_split=us, bias=P[f'{p}.fc1.b'],
+                               act=ACT_GELU)
+                ops.gemm_split(us, P[f'{p}.fc2.w_split'], M, C, 4 * C, out=x, bias=P[f'{p}.fc2.b'], residual=x)
             return x
-        for i in range(self.desc['n_layers']):
+        for i in range(L):
             p = f'{nm}.{i}'
             ops.layernorm(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], out=h)
             ops.gemm(h, P[f'{p}.qkv.w'], out=qkv, bias=P[f'{p}.qkv.b'])
@@ -303,26 +252,18 @@ class SamplerNet:
         self._deferred = None
         P = self.P
         p = f"{self.name}.{self.desc['n_layers'] - 1}"
+        buf = self._buffers(M, C, x.device)
         if 0 < n_rows <= self.TRIM_MAX_ROWS:
             m = int(n_rows)
-            xc, yc = ops.gather_rows(x, rows, m), ops.gather_rows(ys, rows, m)
-            hc, uc = ops.split_rows_empty(m, C, x.device), ops.split_rows_empty(m, 4 * C, x.device)
+            xc, yc = ops.gather_rows(x, rows, m, out=buf['xc'][:m]), ops.gather_rows(ys, rows, m, out=buf['yc'][:m])
+            hc, uc = buf['hc'][:m], buf['uc'][:m]
             compact = True
         else:
             m, xc, yc, compact = M, x, ys, False
-            buf = self._buffers(M, C, x.device)
             hc, uc = buf['h_split'], buf['u_split']
-        if self.fold_ln:
-            pc = ops.ln_partials_empty(m, C, x.device) if compact else self._buffers(M, C, x.device)['ln_part']
-            ops.gemm_split(yc, P[f'{p}.proj.w_split'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc,
-                           out_split=hc, ln_part_out=pc)
-            ops.gemm_split(hc, P[f'{p}.fc1.wf_split'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.bf'],
-                           act=ACT_GELU, ln_in=(pc, P[f'{p}.fc1.cs']))
-        else:
-            ops.gemm_split(yc, P[f'{p}.proj.w_split'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc)
-            ops.layernorm_split(xc, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hc)
-            ops.gemm_split(hc, P[f'{p}.fc1.w_split'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.b'],
-                           act=ACT_GELU)
+        ops.gemm_split(yc, P[f'{p}.proj.w_split'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc)
+        ops.layernorm_split(xc, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hc)
+        ops.gemm_split(hc, P[f'{p}.fc1.w_split'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.b'], act=ACT_GELU)
         ops.gemm_split(uc, P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xc, bias=P[f'{p}.fc2.b'], residual=xc)
         return xc, compact
 
@@ -343,10 +284,17 @@ class SamplerNet:
 
 
 class TorchDeviceNoise:
-    """Default noise source: consumes torch's global generator of the GPU
-    exactly like the reference does (rand per step; one full [B*T, 1024]
-    exponential_ per ACTIVE head, the draw Categorical.sample() makes inside
-    multinomial) so identical seeds give identical tokens."""
+    """Default noise source: torch's global generator of the GPU, consumed exactly like the
+    reference does (rand per step; one full [B*T, 1024] exponential_ per ACTIVE head, the draw
+    Categorical.sample() makes inside multinomial) so identical seeds give identical tokens.
+
+    Normally no draw is materialised: build_schedule reproduces the `rand` draws on the device
+    (t2h_unmask_schedule), the sampling tail computes the elements of the exponential_ tensors it
+    needs, and the generator is advanced to where the reference's would stand.  That emulation of
+    ATen's Philox kernels is verified against the installed torch at first use (`emulation_ok`);
+    if it ever disagrees (another torch / ROCm build) the draws below are made for real."""
+
+    _checked = {}
 
     def __init__(self, device):
         self.device = device
@@ -357,52 +305,136 @@ class TorchDeviceNoise:
     def exponential(self, step, head, shape):
         return torch.empty(shape, device=self.device).exponential_(1.0)
 
-    def reserve_exponential(self, heads, shape):
-        """The same consumption of the generator WITHOUT the draws: advances torch's device generator by
-        what one full `exponential_` of `shape` per head (ascending) would take and returns
-        (seed, {head: offset before its draw}); t2h_sample_heads then computes the few elements it
-        needs of those tensors itself (bit-identical, tests/test_gpu_kernels.py)."""
+    def generator(self):
         dev = torch.device(self.device)
         index = dev.index if dev.index is not None else torch.cuda.current_device()  # (initialises CUDA)
-        gen = torch.cuda.default_generators[index]
-        _, inc = ops.torch_draw_geometry(shape[0] * shape[1], index)
-        off = gen.get_offset()
-        offsets = {}
-        for h in sorted(heads):
-            offsets[h] = off
-            off += inc
-        gen.set_offset(off)
-        return gen.initial_seed(), offsets
+        return torch.cuda.default_generators[index], index
+
+    def emulation_ok(self, n, n_class):
+        """True iff t2h_philox_uniform_f32 / t2h_philox_exponential_f32 reproduce this torch build's
+        `rand(n)` / `empty(n * n_class).exponential_()` bit for bit (generator state restored)."""
+        gen, index = self.generator()
+        key = (index, int(n), int(n_class))
+        if key not in self._checked:
+            state = gen.get_state()
+            try:
+                seed, off = gen.initial_seed(), gen.get_offset()
+                want_u = torch.rand(n, device=self.device)
+                off_e = gen.get_offset()
+                want_e = torch.empty(n * n_class, device=self.device).exponential_(1.0)
+                got_u = ops.philox_uniform(seed, off, n, self.device)
+                got_e = ops.philox_exponential(seed, off_e, n * n_class, self.device)
+                ok = bool(torch.equal(want_u, got_u)) and bool(torch.equal(want_e, got_e))
+            finally:
+                gen.set_state(state)
+            if not ok:
+                import warnings
+                warnings.warn('text2human_amd: the in-kernel reproduction of torch\'s Philox draws does not match '
+                              'this torch / ROCm build; falling back to explicit torch draws (slower, same tokens)')
+            self._checked[key] = ok
+        return self._checked[key]
 
 
 class SplitOverflowError(_lib.T2HError):
     """An activation of the split-precision sampler left fp16's range."""
 
 
-def check_split_overflow(what='sampler'):
+def check_split_overflow(what='sampler', knob='T2H_SPLIT_GEMM'):
     """Raises if a split-row producer flagged |x| >= 65504 since the last check (the fp16
     planes would hold inf / NaN).  There is deliberately no silent fallback: the caller reruns
-    with T2H_SPLIT_GEMM=0 (exact-fp32 matrix instructions)."""
+    with the exact-fp32 kernels."""
     if ops.split_overflow(reset=True):
         raise SplitOverflowError(
             f'{what}: an activation reached |x| >= 65504, outside the range of the 2 x fp16 split '
-            'representation (include/t2h_hip.h); the result is invalid.  Rerun with T2H_SPLIT_GEMM=0 '
+            f'representation (include/t2h_hip.h); the result is invalid.  Rerun with {knob}=0 '
             '(exact-fp32 kernels).')
 
 
+class SampleSchedule:
+    """Device-resident schedule of one sample_tokens run (see schedule.py): rows of round r =
+    rows[start[r]:start[r + 1]], each with its own noise reference."""
+
+    def __init__(self, rows, start, round_steps, noise_kind, seed=None, offsets=None, expo_rows=None, slots=None):
+        self.rows, self.start, self.round_steps = rows, start, round_steps
+        self.noise_kind, self.seed, self.offsets, self.expo_rows, self.slots = noise_kind, seed, offsets, expo_rows, slots
+        self.n_rounds = len(start) - 1
+        self.max_rows = int(max(int(start[r + 1] - start[r]) for r in range(self.n_rounds))) if self.n_rounds else 0
+
+    def row_noise(self, lo, hi):
+        if self.noise_kind == 'philox':
+            return ('philox', self.seed, self.offsets[lo:hi])
+        return ('explicit', self.expo_rows, self.slots[lo:hi])
+
+
+def build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact=True):
+    """The unmasking schedule + RNG bookkeeping of one sample_fn call (schedule.py), consuming
+    `noise` exactly as the reference's loop would (models/sample_model.py:279-306)."""
+    B, T = tex_tok.shape
+    dev = tex_tok.device
+    n = B * T
+    tex_flat = tex_tok.reshape(-1).contiguous()
+    tex_host = tex_flat.cpu().numpy()
+    if isinstance(noise, TorchDeviceNoise) and noise.emulation_ok(n, n_class):
+        # one launch reproduces every `rand` draw; one host read fetches the whole schedule
+        gen, _ = noise.generator()
+        seed, off0 = gen.initial_seed(), gen.get_offset()
+        step_dev, mask_dev, rand_inc, expo_inc = ops.unmask_schedule(seed, off0, tex_flat, sample_steps, n_books, n_class)
+        step_of_row = step_dev.cpu().numpy()
+        head_mask = mask_dev.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        _, expo_off, final = schedule.draw_offsets(head_mask, sample_steps, off0, rand_inc, expo_inc, n_books)
+        gen.set_offset(final)  # where the reference's generator stands after its loop
+        order, start, round_steps = schedule.group_rounds(step_of_row, B, T, compact)
+        offs = expo_off[step_of_row[order], tex_host[order]]
+        assert (offs >= 0).all()
+        return SampleSchedule(torch.from_numpy(order.astype(np.int32)).to(dev), start, round_steps, 'philox', seed=seed,
+                              offsets=torch.from_numpy(offs).to(dev))
+    # explicit draws (tests replaying CPU noise; the emulation fallback): the reference's own loop
+    # order, with the rows each head needs copied out of its full draw
+    unmasked = torch.zeros(n, dtype=torch.uint8, device=dev)
+    changes = torch.zeros(n, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(n_books + 1, dtype=torch.int32, device=dev)
+    rows = torch.empty(n, dtype=torch.int32, device=dev)
+    step_of_row = np.zeros(n, dtype=np.int32)
+    slot_of_row = np.zeros(n, dtype=np.int32)
+    expo_rows = torch.empty((n, n_class), dtype=torch.float32, device=dev)
+    fill = 0
+    for t in range(sample_steps, 0, -1):
+        rnd = noise.uniform(t, (B, T)).to(dev, torch.float32).contiguous()
+        counts.zero_()
+        ops.unmask_step(rnd, t, unmasked, changes, tex_flat, counts, rows, n_books)
+        c = counts.cpu().numpy()
+        if c[n_books] == 0:
+            continue
+        rows_t = np.sort(rows[:int(c[n_books])].cpu().numpy())
+        step_of_row[rows_t] = t
+        for h in np.nonzero(c[:n_books])[0]:  # ascending: the reference's draw order
+            e = noise.exponential(t, int(h), (n, n_class)).to(dev, torch.float32).contiguous()
+            rh = rows_t[tex_host[rows_t] == h]
+            ops.gather_rows(e, torch.from_numpy(rh.astype(np.int32)).to(dev), len(rh), out=expo_rows[fill:fill + len(rh)])
+            slot_of_row[rh] = np.arange(fill, fill + len(rh), dtype=np.int32)
+            fill += len(rh)
+    assert fill == n, (fill, n)
+    order, start, round_steps = schedule.group_rounds(step_of_row, B, T, compact)
+    return SampleSchedule(torch.from_numpy(order.astype(np.int32)).to(dev), start, round_steps, 'explicit',
+                          expo_rows=expo_rows, slots=torch.from_numpy(slot_of_row[order]).to(dev))
+
+
 def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise=None,
-                  n_books=18, step_hook=None):
+                  n_books=18, step_hook=None, round_hook=None, compact=None):
     """BaseSampleModel.sample_fn (models/sample_model.py:256-328) on device.
 
-    Per step: one tiny kernel does the mask algebra and counts the changed
-    tokens per texture head; ONE host read of those 18 counters decides which
-    heads draw noise (the reference's data-dependent `if`, :301-302, which
-    gates RNG consumption) -- it is issued before the transformer launches so
-    the host wait overlaps the GPU work; then the texture-routed sampling tail
-    runs once per active head.  Returns int64 [18, B*T] (-1 off-texture).
+    The unmasking schedule and every generator offset are computed up front (build_schedule: they
+    do not depend on the transformer), so the loop below never reads anything back from the GPU.
+    compact=True (default; T2H_COMPACT_ROUNDS=0 or a step_hook turn it off): every sample advances
+    through its own active steps -- a (sample, step) pair that changes no token is never evaluated,
+    its logits would not be read (sample_model.py:300-317) -- which takes ~13.5 % fewer transformer
+    evaluations than the reference's synchronous loop and gives the same tokens bit for bit.
+    compact=False: one round per step that changes a token, all samples at that step.
+    Returns int64 [18, B*T] (-1 off-texture).
 
-    step_hook(t, x_t, out) (tests only) runs after every step and may overwrite x_t in
-    place, e.g. to teacher-force the reference's trajectory."""
+    Test hooks, called after each round and allowed to overwrite x_t in place (teacher forcing):
+    round_hook(r, steps, x_t, out) with steps[b] = the step sample b just took (0 = idle);
+    step_hook(t, x_t, out) (compact=False only; steps that change no token are skipped)."""
     P, nm = net.P, net.name
     B, T = segm_tok.shape
     dev = segm_tok.device
@@ -411,48 +443,38 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     lo, hi = int(tex_tok.min()), int(tex_tok.max())
     if lo < 0 or hi >= n_books:
         raise _lib.T2HError(f'texture ids must lie in [0, {n_books}), got [{lo}, {hi}]')
+    split = bool(getattr(net, 'split', False))
+    if split:
+        ops.split_overflow(reset=True)  # a flag left by an earlier stage is not this run's
+    if compact is None:
+        compact = step_hook is None and os.environ.get('T2H_COMPACT_ROUNDS', '1') != '0'
+    if compact and step_hook is not None:
+        raise ValueError('step_hook needs compact=False (samples are at different steps in a compact round)')
     noise = noise or TorchDeviceNoise(dev)
     n = B * T
-    x_t = torch.full((B, T), mask_id, dtype=torch.int64, device=dev)
-    unmasked = torch.zeros(n, dtype=torch.uint8, device=dev)
-    changes = torch.zeros(n, dtype=torch.uint8, device=dev)
-    out = torch.full((n_books, n), -1, dtype=torch.int64, device=dev)
-    counts = torch.zeros(n_books + 1, dtype=torch.int32, device=dev)  # per head + total
-    counts_host = torch.zeros(n_books + 1, dtype=torch.int32).pin_memory()
-    rows = torch.empty(n, dtype=torch.int32, device=dev)               # compact list of changed rows
-    tex_flat = tex_tok.reshape(-1).contiguous()
     n_class = P[f'{nm}.heads'].shape[1]
-    ev = torch.cuda.Event()
-    for t in range(sample_steps, 0, -1):
-        rnd = noise.uniform(t, (B, T)).to(dev, torch.float32).contiguous()
-        counts.zero_()
-        ops.unmask_step(rnd, t, unmasked, changes, tex_flat, counts, rows, n_books)
-        counts_host.copy_(counts, non_blocking=True)
-        ev.record()
-        defer = bool(getattr(net, 'split', False) and getattr(net, 'split_mha', False) and net.n_streams == 1
-                     and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
-        hidden = net.hidden(x_t, segm_tok, tex_tok, defer_tail=defer)
-        ev.synchronize()
-        active = torch.nonzero(counts_host[:n_books]).flatten().tolist()
-        if not active:
-            continue
-        compact = False
-        if defer and net._deferred is not None:
-            hidden, compact = net.finish_tail(rows, int(counts_host[n_books]))
-        # the reference's draws: one full [n, 1024] tensor per active head in ascending head order.
-        # On torch's device generator they are not materialised: the generator is advanced as if,
-        # and the sampling tail computes the elements of those tensors it needs (the changed rows).
-        # Other noise sources (tests replaying CPU draws) hand over explicit tensors.
-        if hasattr(noise, 'reserve_exponential') and os.environ.get('T2H_PHILOX_TAIL', '1') != '0':
-            expo, philox = {}, noise.reserve_exponential(active, (n, n_class))
-        else:
-            expo = {cb: noise.exponential(t, cb, (n, n_class)).to(dev, torch.float32).contiguous() for cb in active}
-            philox = None
-        ops.sample_heads(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'], expo, rows,
-                         int(counts_host[n_books]), tex_flat, temp, x_t, out, philox=philox, hidden_compact=compact)
+    tex_flat = tex_tok.reshape(-1).contiguous()
+    sched = build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact)
+    net.last_stats = schedule.stats(sched.round_steps, sample_steps)
+    x_t = torch.full((B, T), mask_id, dtype=torch.int64, device=dev)
+    out = torch.full((n_books, n), -1, dtype=torch.int64, device=dev)
+    logits_ws = torch.empty((max(sched.max_rows, 1), n_class), dtype=torch.float32, device=dev)
+    defer = bool(split and getattr(net, 'split_mha', False) and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
+    for r in range(sched.n_rounds):
+        lo, hi = int(sched.start[r]), int(sched.start[r + 1])
+        hidden = net.hidden(x_t, segm_tok, tex_tok, defer_tail=True) if defer else net.hidden(x_t, segm_tok, tex_tok)
+        rows_r = sched.rows[lo:hi]
+        hidden_compact = False
+        if defer:
+            hidden, hidden_compact = net.finish_tail(rows_r, hi - lo)
+        ops.sample_heads(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'], {}, rows_r, hi - lo, tex_flat,
+                         temp, x_t, out, row_noise=sched.row_noise(lo, hi), hidden_compact=hidden_compact,
+                         logits_ws=logits_ws)
+        if round_hook is not None:
+            round_hook(r, sched.round_steps[r], x_t, out)
         if step_hook is not None:
-            step_hook(t, x_t, out)
-    if net.split:
+            step_hook(int(sched.round_steps[r].max()), x_t, out)
+    if split:
         check_split_overflow('index sampler')
     return out
 

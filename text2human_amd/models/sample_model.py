@@ -50,7 +50,8 @@ class BaseSampleModel():
         # default: split-precision (2 x fp16 planes, three products) like the sampler's Linears.
         # The tokenizer encoder, the index-prediction UNet and the parsing generator stay exact
         # fp32: their outputs are argmin / argmax decisions that must match the reference bit for bit.
-        if os.environ.get('T2H_SPLIT_CONV', '1') != '0':
+        self.split_conv = os.environ.get('T2H_SPLIT_CONV', '1') != '0'
+        if self.split_conv:
             weights.add_split_conv_weights(P, 'dec')
             weights.add_split_conv_weights(P, 'res')
         self.decoder = engine.VQGANStack(P, 'dec', d_dec)
@@ -75,9 +76,8 @@ class BaseSampleModel():
         # (T2H_SPLIT_MHA=0 keeps the attention on the exact-fp32 kernel)
         split = os.environ.get('T2H_SPLIT_GEMM', '1') != '0'
         split_mha = os.environ.get('T2H_SPLIT_MHA', '1') != '0'
-        n_streams = int(os.environ.get('T2H_SAMPLER_STREAMS', '1'))
         self.sampler_fn = engine.SamplerNet(P, d_tf, self.opt['bert_n_head'], 'tf', split=split,
-                                            split_mha=split_mha, n_streams=n_streams)
+                                            split_mha=split_mha)
 
     # ------------------------------------------------------------ helpers
     def _texture_tokens(self, texture_mask):
@@ -174,6 +174,8 @@ class BaseSampleModel():
             u8s.append(res[1])
             if return_inter:
                 inters.append(res[2])
+        if self.split_conv:  # split-precision decoder convolutions: loud on fp16-range overflow
+            engine.check_split_overflow('VQGAN refine / decode', knob='T2H_SPLIT_CONV')
         img = torch.cat(imgs, 0) if len(imgs) > 1 else imgs[0]
         u8 = (torch.cat(u8s, 0) if len(u8s) > 1 else u8s[0]) if want_u8 else None
         if return_inter:

@@ -306,21 +306,14 @@ def pack_split_rows_host(w):
     return planes.view(torch.int16)
 
 
-def ln_partials_empty(M, C, device):
-    """Per (row, 32-column slice) (mean, M2) partials of a [M, C] tensor (t2h_gemm_split_args.ln_part_out)."""
-    return torch.empty(M, C // 32, 2, dtype=torch.float32, device=device)
-
-
 def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE,
-               vt=None, vt_col0=0, vt_T=0, vt_hd=64, ln_part_out=None, ln_in=None, ln_eps=1e-5):
+               vt=None, vt_col0=0, vt_T=0, vt_hd=64):
     """C = act(A @ W^T + bias) + residual on the fp16 matrix cores at fp32-class
     accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
     split-row form `out_split` of the result.  With `vt` the output columns from
     `vt_col0` on go to the transposed value planes of mha_split instead
-    (t2h_gemm_split_args.Vt).  Folded LayerNorm (include/t2h_hip.h): `ln_part_out` receives the row
-    partials of the result; `ln_in=(partials of A's rows, column sums of W)` makes the epilogue
-    evaluate rstd (acc - mean colsum) + bias, i.e. LayerNorm(A) @ W0^T for W = W0 diag(gamma)."""
-    _chk_f32(out, bias, residual, ln_part_out)
+    (t2h_gemm_split_args.Vt)."""
+    _chk_f32(out, bias, residual)
     g = _lib.GemmSplitArgs()
     g.A, g.B = a_split.data_ptr(), w_split.data_ptr()
     g.C = out.data_ptr() if out is not None else None
@@ -333,14 +326,6 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     g.epi_act = act
     if vt is not None:
         g.Vt, g.vt_col0, g.vt_T, g.vt_hd = vt.data_ptr(), vt_col0, vt_T, vt_hd
-    if ln_part_out is not None:
-        assert tuple(ln_part_out.shape) == (M, N // 32, 2), ln_part_out.shape
-        g.ln_part_out = ln_part_out.data_ptr()
-    if ln_in is not None:
-        part, colsum = ln_in
-        _chk_f32(part, colsum)
-        assert tuple(part.shape) == (M, K // 32, 2) and colsum.numel() == N, (part.shape, colsum.shape)
-        g.ln_part_in, g.ln_colsum, g.ln_eps = part.data_ptr(), colsum.data_ptr(), ln_eps
     lib = _lib.load()
     if _prof is not None:
         _prof['count'] += 1
@@ -490,6 +475,33 @@ def philox_exponential(seed, offset, numel, device):
     return out
 
 
+def philox_uniform(seed, offset, numel, device):
+    """What `torch.rand(numel, device=device)` returns on a generator with this seed / offset
+    (t2h_philox_uniform_f32)."""
+    out = torch.empty(numel, device=device, dtype=torch.float32)
+    gt, _ = torch_draw_geometry(numel, device)
+    check(_lib.load().t2h_philox_uniform_f32(int(seed), int(offset), gt, _p(out), numel, _stream()),
+          't2h_philox_uniform_f32')
+    return out
+
+
+def unmask_schedule(seed, offset, tex, steps, n_heads, n_class):
+    """The whole unmasking schedule of a sampling run on torch's device generator (seed, offset before
+    the first draw) in one launch (t2h_unmask_schedule).  tex int64 [n].  Returns
+    (step_of_row int32 [n], head_mask int32 [steps + 1], rand_inc, expo_inc) -- device tensors."""
+    _chk_i64(tex)
+    n = tex.numel()
+    dev = tex.device
+    rand_gt, rand_inc = torch_draw_geometry(n, dev)
+    _, expo_inc = torch_draw_geometry(n * n_class, dev)
+    step_of_row = torch.empty(n, dtype=torch.int32, device=dev)
+    head_mask = torch.empty(steps + 1, dtype=torch.int32, device=dev)
+    check(_lib.load().t2h_unmask_schedule(int(seed), int(offset), rand_gt, rand_inc, expo_inc, _p(tex), n, int(steps),
+                                          int(n_heads), _p(step_of_row), _p(head_mask), _stream()),
+          't2h_unmask_schedule')
+    return step_of_row, head_mask, rand_inc, expo_inc
+
+
 def gather_rows(src, rows, n_rows, out=None):
     """out[i] = src[rows[i]] (rows int32 on the device, first n_rows used); src 2-D+ contiguous, any dtype
     whose row is a multiple of 16 bytes."""
@@ -502,12 +514,14 @@ def gather_rows(src, rows, n_rows, out=None):
 
 
 def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex, temp, x_t, out_idx, split=True,
-                 philox=None, hidden_compact=False):
+                 philox=None, hidden_compact=False, row_noise=None, logits_ws=None):
     """All heads in one launch: `rows` (int32, first n_rows valid) are the changed token
     rows, expo_by_head {head: [n, n_class] Exp(1) draw}, w_heads [n_heads, n_class, C],
     out_idx [n_heads, n].  philox = (seed, {head: generator offset}): the noise of the listed heads is
     computed in the kernel as the corresponding elements of torch's full-tensor exponential_ draws
-    instead of being read from expo_by_head."""
+    instead of being read from expo_by_head.  row_noise (row lists that mix sampling steps):
+    ('philox', seed, offsets int64 [>= n_rows]) = per-listed-row generator offsets, or
+    ('explicit', expo_rows f32 [*, n_class], slots int32 [>= n_rows]) = per-listed-row explicit draws."""
     _chk_f32(hidden, lnf_g, lnf_b, w_heads, *expo_by_head.values())
     C = hidden.shape[1]
     n = out_idx.shape[1]
@@ -523,10 +537,25 @@ def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex,
     a.rows, a.tex, a.x_t, a.out_idx = rows.data_ptr(), tex.data_ptr(), x_t.data_ptr(), out_idx.data_ptr()
     a.temp, a.n_rows, a.n, a.C, a.n_class, a.n_heads = float(temp), int(n_rows), n, C, n_class, n_heads
     a.hidden_compact = int(bool(hidden_compact))
-    if (split or philox is not None or hidden_compact) and n_rows > 0:  # logits scratch: 8 workgroups per row share the weight stream
-        ws = torch.empty((int(n_rows), n_class), device=hidden.device, dtype=torch.float32)
+    if (split or philox is not None or hidden_compact or row_noise is not None) and n_rows > 0:
+        # logits scratch: 8 workgroups per row share the weight stream
+        ws = logits_ws if logits_ws is not None else torch.empty((int(n_rows), n_class), device=hidden.device,
+                                                                 dtype=torch.float32)
+        assert ws.numel() >= int(n_rows) * n_class and ws.dtype == torch.float32
         a.logits_ws = ws.data_ptr()
-    if philox is not None:
+    if row_noise is not None:
+        if row_noise[0] == 'philox':
+            _, seed, offs = row_noise
+            assert offs.dtype == torch.int64 and offs.is_cuda and offs.numel() >= int(n_rows)
+            a.philox_seed, a.row_philox_offset = int(seed), offs.data_ptr()
+            a.philox_grid_threads = torch_draw_geometry(n * n_class, hidden.device)[0]
+        else:
+            _, erows, slots = row_noise
+            _chk_f32(erows)
+            assert erows.is_contiguous() and erows.shape[-1] == n_class
+            assert slots.dtype == torch.int32 and slots.is_cuda and slots.numel() >= int(n_rows)
+            a.expo_rows, a.expo_slot = erows.data_ptr(), slots.data_ptr()
+    elif philox is not None:
         seed, offsets = philox
         a.philox_seed = int(seed)
         for h, off in offsets.items():

@@ -1,0 +1,88 @@
+"""The unmasking schedule of `sample_fn` (models/sample_model.py:279-317), computed BEFORE the
+transformer runs.
+
+In the reference loop the tokens that change at step t are `rand([B,T]) < 1/t` minus the ones
+already unmasked, and the only other consumer of the generator is one full `[B*T, n_class]`
+`exponential_` draw per head that has a changed token at that step.  Nothing of this depends on
+the transformer's logits: the whole schedule -- which row changes at which step, and the
+generator offset of every draw -- is a function of the seed and of the texture map.  Two
+consequences, both used by engine.sample_tokens:
+
+* no host round trip inside the sampling loop (the reference's data-dependent `if`,
+  sample_model.py:301-302, is resolved up front);
+* a sample whose tokens do not change at a step never has its logits read there, its `x_t` does
+  not move, and samples never interact (attention is per sample): every sample can walk through
+  ITS OWN active steps.  Round r evaluates, for every sample, its r-th active step -- about
+  0.865 * steps rounds of the full batch instead of `steps`, with bit-identical tokens.
+
+This module is host-side integer bookkeeping (numpy); the draws themselves are reproduced on the
+device (t2h_unmask_schedule / t2h_sample_heads) or taken from an explicit noise source.
+"""
+import numpy as np
+
+
+def draw_offsets(head_mask, steps, offset0, rand_inc, expo_inc, n_heads):
+    """Generator offsets of the reference's draws.
+
+    head_mask[t] (t = steps .. 1): bit h set iff head h samples at step t.  Returns
+    (rand_off int64 [steps + 1], expo_off int64 [steps + 1, n_heads] (-1 where the head draws
+    nothing), final offset): the generator holds rand_off[t] before the `rand` of step t and
+    expo_off[t, h] before head h's `exponential_` of that step (heads in ascending order)."""
+    head_mask = np.asarray(head_mask, dtype=np.int64)
+    rand_off = np.zeros(steps + 1, dtype=np.int64)
+    expo_off = np.full((steps + 1, n_heads), -1, dtype=np.int64)
+    cur = int(offset0)
+    for t in range(steps, 0, -1):
+        rand_off[t] = cur
+        cur += int(rand_inc)
+        m = int(head_mask[t])
+        for h in range(n_heads):
+            if (m >> h) & 1:
+                expo_off[t, h] = cur
+                cur += int(expo_inc)
+    return rand_off, expo_off, cur
+
+
+def group_rounds(step_of_row, B, T, compact=True):
+    """Rounds of the sampling loop.
+
+    step_of_row int [B*T]: the step (>= 1) at which each token row changes.  compact=True: round r
+    of sample b is its r-th active step (descending t); compact=False: round r is the r-th step (of
+    any sample) that changes a token, for every sample alike -- the reference's own loop minus the
+    steps that change nothing.  Returns
+      order        int64 [B*T]   row ids sorted by (round, row),
+      start        int64 [R + 1] order[start[r]:start[r + 1]] are the rows of round r,
+      round_steps  int32 [R, B]  the step sample b is at in round r (0 = idle in that round)."""
+    steps = np.asarray(step_of_row, dtype=np.int64).reshape(B, T)
+    if steps.min() < 1:
+        raise ValueError('every token row must have a step >= 1')
+    if compact:
+        uniq = [np.unique(steps[b]) for b in range(B)]            # ascending
+    else:
+        g = np.unique(steps)
+        uniq = [g] * B
+    n_rounds = max(len(u) for u in uniq)
+    rnd = np.empty((B, T), dtype=np.int64)
+    round_steps = np.zeros((n_rounds, B), dtype=np.int32)
+    for b in range(B):
+        u = uniq[b]
+        rnd[b] = len(u) - 1 - np.searchsorted(u, steps[b])       # descending t = ascending round
+        if compact:
+            round_steps[:len(u), b] = u[::-1]
+        else:
+            present = np.isin(u, steps[b])
+            round_steps[:len(u), b] = np.where(present, u, 0)[::-1]
+    flat = rnd.reshape(-1)
+    order = np.lexsort((np.arange(B * T), flat)).astype(np.int64)
+    start = np.searchsorted(flat[order], np.arange(n_rounds + 1)).astype(np.int64)
+    return order, start, round_steps
+
+
+def stats(round_steps, steps):
+    """Evaluation counts for the bench line: (sample, step) pairs the reference evaluates, pairs that
+    change a token (the ones whose logits are read), rounds launched."""
+    n_rounds, B = round_steps.shape
+    return dict(rounds=int(n_rounds), steps=int(steps), batch=int(B),
+                sample_steps_possible=int(B * steps),
+                sample_steps_needed=int((round_steps > 0).sum()),
+                sample_steps_launched=int(n_rounds * B))

@@ -169,21 +169,7 @@ def add_split_conv_weights(P, dst):
     engine.check_split_overflow(f'weights of {dst}')
 
 
-def fold_layernorm(w, b, gamma, beta):
-    """Linear(LayerNorm(x)) with the affine part folded into the Linear (host, fp64):
-    returns (split rows of W diag(gamma), column sums of those split-rounded weights, b + W beta)."""
-    from . import ops as _ops
-    wf = (w.double() * gamma.double()[None, :]).float()
-    hi, lo = _ops.split_planes_host(wf)
-    cs = (hi.double() + lo.double() / _ops.SPLIT_LO_SCALE).sum(1).float()
-    return _ops.pack_split_rows_host(wf), cs, (b.double() + w.double() @ beta.double()).float()
-
-
-def pack_transformer(P, sd, dst='tf', fold_ln=None):
-    """fold_ln: also pack the LayerNorm-folded q|k|v / fc1 weights (engine.SamplerNet.fold_ln;
-    default: the T2H_FOLD_LN=1 opt-in)."""
-    if fold_ln is None:
-        fold_ln = os.environ.get('T2H_FOLD_LN', '0') == '1'
+def pack_transformer(P, sd, dst='tf'):
     n_layers = _count(sd, 'blocks')
     P.put(f'{dst}.tok_emb', sd['tok_emb.weight'])
     P.put(f'{dst}.pos_emb', sd['pos_emb'][0])
@@ -202,16 +188,6 @@ def pack_transformer(P, sd, dst='tf', fold_ln=None):
                          ('fc2', f'{s}.mlp.2.weight')):
             w = P[f'{d}.qkv.w'].cpu() if key is None else sd[key]
             P.t[f'{d}.{lin}.w_split'] = _ops.pack_split_rows_host(w).to(P.device)
-        # LayerNorm folded into the Linear that consumes it (t2h_gemm_split_args.ln_part_in):
-        # LN(x) W^T + b = rstd (x (W diag g)^T - mean colsum) + (b + W beta); colsum is taken over the
-        # split-ROUNDED weights, the values the matrix cores multiply, so the mean cancels exactly
-        for lin, ln in (('qkv', 'ln1'), ('fc1', 'ln2')) if fold_ln else ():
-            w = P[f'{d}.qkv.w'].cpu() if lin == 'qkv' else sd[f'{s}.mlp.0.weight']
-            b = P[f'{d}.qkv.b'].cpu() if lin == 'qkv' else sd[f'{s}.mlp.0.bias']
-            wf_split, cs, bf = fold_layernorm(w, b, sd[f'{s}.{ln}.weight'], sd[f'{s}.{ln}.bias'])
-            P.t[f'{d}.{lin}.wf_split'] = wf_split.to(P.device)
-            P.put(f'{d}.{lin}.cs', cs)
-            P.put(f'{d}.{lin}.bf', bf)
         P.put(f'{d}.proj.w', sd[f'{s}.attn.proj.weight'])
         P.put(f'{d}.proj.b', sd[f'{s}.attn.proj.bias'])
         P.put(f'{d}.fc1.w', sd[f'{s}.mlp.0.weight'])

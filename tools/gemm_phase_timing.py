@@ -3,7 +3,7 @@ s_memrealtime stamps (100 MHz) per workgroup: entry, prologue done, main loop do
 stores issued, stores acknowledged.  Prints the median phase lengths, the dispatch skew and the
 span first-entry -> last-ack next to the event-timed launch.  GPU only.
 
-    python tools/gemm_phase_timing.py [cfgs=4,6,8] [batch=8]
+    python tools/gemm_phase_timing.py [cfgs=6,8] [batch=8]
 """
 import ctypes
 import os
@@ -24,7 +24,7 @@ subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', 
                 f'-I{ROOT}/include', '-DT2H_GEMM_TIMING', *[f'-D{d}' for d in DEFS], *(["-DT2H_DMA_POLICY=\" " + os.environ['T2H_DMA_POLICY'].replace('-', '') + "\""] if os.environ.get('T2H_DMA_POLICY') else []), os.path.join(csrc, 'api.hip'),
                 os.path.join(csrc, 'gemm_split.hip'), '-o', so], check=True)
 lib = ctypes.CDLL(so)
-CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 else [4, 6]
+CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 else [6, 8]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 M = 512 * B
 g0 = torch.Generator().manual_seed(0)

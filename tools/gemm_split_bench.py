@@ -26,7 +26,7 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    CFGS = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 4, 6]
+    CFGS = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 6, 8]
     M = B * 512
     g = torch.Generator().manual_seed(0)
     shapes = {'qkv': (M, 1536, 512), 'proj': (M, 512, 512), 'fc1': (M, 2048, 512), 'fc2': (M, 512, 2048)}

@@ -3,7 +3,7 @@ split-row + Vt outputs, proj with the residual, fc1 with the GELU split-row epil
 residual) timed per tile configuration of t2h_gemm_split_f32: interleaved rounds in one process,
 median per call, plus the back-to-back chain of all four.  GPU only.
 
-    python tools/sampler_gemm_bench.py [batch=8] [cfgs=-1,0,4,6,8] [rounds=7]
+    python tools/sampler_gemm_bench.py [batch=8] [cfgs=-1,0,6,8] [rounds=7]
 """
 import os
 import statistics
@@ -20,7 +20,7 @@ C, H, T = 512, 8, 512
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    cfgs = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [-1, 0, 4, 6]
+    cfgs = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [-1, 0, 6, 8]
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
     M = B * T
     g = torch.Generator().manual_seed(0)
