@@ -6,17 +6,23 @@
 One "step" = one full pass of the hot path over one batch of synthetic inputs per GPU, all
 inputs resident in HBM before the timed region:
 
-  parsing (default; BASELINE.json configs[1], sharded = configs[3]): `sample_from_parsing`,
-          batch 8 per GPU: segm tokenizer -> 256-step texture-aware transformer index sampler
-          -> index refinement -> hierarchical VQGAN decode -> uint8 512x256 images;
+  parsing (default; BASELINE.json configs[1]): `sample_from_parsing`, batch 8 per GPU: segm
+          tokenizer -> 256-step texture-aware transformer index sampler -> index refinement ->
+          hierarchical VQGAN decode -> uint8 512x256 images;
   pose    (configs[2]): `sample_from_pose`, batch 32 per GPU: ShapeUNet parsing generator ->
           tokenizer -> sampler -> refine -> decode;
   hires   (configs[4]): the 1024x512 upscaled hierarchy (SURVEY.md 8(d) interpretation: sample at
           32x16, nearest-x2 both quantised latents, fully-convolutional decode), batch 8 per GPU.
 
+The default run (`--config parsing`) also times, inside the same command, the other
+configurations for 1 warm-up + 2 steps each and reports them under "other_configs": configs[3]'s
+per-GPU share (sample_from_parsing at 32 images per GPU; its global batch at N = 8 IS configs[3]),
+and at N = 1 configs[2] (pose, B = 32) and configs[4]'s per-GPU share (hires, B = 8).
+
 For N > 1 the driver launches this file with torch.distributed.run; images are independent so
-the batch is sharded across ranks with no data-path collective (weak scaling, per-rank batch
-fixed); weights are synthesised on rank 0 and broadcast over RCCL.
+the batch is sharded across ranks with no data-path collective (weak scaling: the headline line
+keeps configs[1]'s 8 images per GPU at every N, "other_configs.parsing_b32" keeps 32 per GPU);
+weights are synthesised on rank 0 and broadcast over RCCL.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
   roofline     -- dominant kernel (the split-precision GEMM of the sampler Linears: three fp16
@@ -24,7 +30,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) including
                   launch stream: `frac` = EXECUTED fp16 matrix FLOP/s over the 2.5 PFLOP/s dense
                   16-bit peak, `frac_useful` = the reference's fp32 FLOP count over the same peak;
   stages       -- per-stage times (HIP events) with the decode stage's compute AND HBM fractions;
-  parity       -- the split-precision step against the exact-fp32 step on the same batch / seed;
+  stages       also carry the sampler's schedule: (sample, step) pairs possible / needed / evaluated;
+  parity       -- the split-precision step (sampler AND decoder) against the exact-fp32 step on the
+                  same batch / seed: tokens, bottom indices, image;
   cpu_baseline -- the oracle (CPU port of the reference path) timed on this box's host cores.
 """
 import argparse
@@ -49,11 +57,15 @@ GFLOP_IMAGE = dict(sampler_step=99.858, tokenizer=40.49, refine=2.19, decode=562
 DECODE_BYTES_IMAGE = dict(parsing=1.870e9, hires=7.48e9)
 DECODE_WEIGHT_BYTES = 216.5e6
 WORKLOADS = {
-    'parsing': dict(batch=8, ref='BASELINE.json configs[1] (configs[3] when sharded)',
+    'parsing': dict(batch=8, ref='BASELINE.json configs[1]', metric='512x256 images/sec (sample_from_parsing)',
                     desc='sample_from_parsing.yml, top+bottom VQGAN decode + index sampler'),
-    'pose': dict(batch=32, ref='BASELINE.json configs[2]',
+    'parsing_b32': dict(batch=32, ref="BASELINE.json configs[3]'s per-GPU share: batch 256 sharded over 8 GPUs",
+                        metric='512x256 images/sec (sample_from_parsing)',
+                        desc='sample_from_parsing.yml, top+bottom VQGAN decode + index sampler'),
+    'pose': dict(batch=32, ref='BASELINE.json configs[2]', metric='512x256 images/sec (sample_from_pose)',
                  desc='sample_from_pose.yml (ParsingGen -> hierarchy VQGAN -> sampler end-to-end)'),
-    'hires': dict(batch=8, ref='BASELINE.json configs[4]',
+    'hires': dict(batch=8, ref="BASELINE.json configs[4]'s per-GPU share: batch 64 over 8 GPUs",
+                  metric='1024x512 images/sec (upscaled hierarchy)',
                   desc='1024x512 upscaled hierarchy (32x16 sampling, nearest-x2 latents, 64x32 / 128x64 '
                        'token grids through the fully-convolutional decoders)'),
 }
@@ -64,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', choices=sorted(WORKLOADS), default='parsing')
+    ap.add_argument('--config', choices=['parsing', 'pose', 'hires'], default='parsing')
     ap.add_argument('--batch', type=int, default=0, help='images per GPU per step (0 = the config default)')
     ap.add_argument('--sample-steps', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -75,6 +87,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-exact-fp32', action='store_true',
                     help='skip the extra steps on the exact-fp32 (v_mfma_f32_32x32x2_f32) sampler kernels')
     ap.add_argument('--exact-steps', type=int, default=3)
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the "other_configs" legs (configs[3] per-GPU share, pose B=32, hires B=8) of the default run')
+    ap.add_argument('--other-steps', type=int, default=2, help='timed steps of each other_configs leg (after 1 warm-up)')
     ap.add_argument('--eager-gpu-baseline', action='store_true',
                     help='also time the oracle sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
     ap.add_argument('--stub-model', action='store_true',
@@ -167,30 +182,59 @@ def eager_gpu_baseline(model, batch, sds, n_sub, dev):
                 sample=f'B={tok.shape[0]}, {n_sub} sampler steps each (the sampler is 97% of the path)')
 
 
-# --------------------------------------------------------------------------- PMC side data
+# --------------------------------------------------------------------------- profile side data
 
 
-def pmc_traffic(kernel_label):
-    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be read from inside
-    the benchmark; they come from the separate rocprofv3 --pmc passes of this same bench command
-    committed under profiles/ (FETCH_SIZE and WRITE_SIZE in their own passes, gfx950 FETCH x2
-    correction, tools/pmc_summary.py) -- launch-weighted over the kernel's shapes."""
-    for name in ('r02_pmc_summary.json', 'r01_pmc_summary.json'):
-        path = os.path.join(ROOT, 'profiles', name)
-        if os.path.exists(path):
-            break
-    else:
-        return {'traffic': None}
+def kernel_src_digest():
+    """sha256 over the kernel sources + the C-ABI header: profile summaries under profiles/ carry
+    the digest of the tree they were taken from (tools/pmc_summary.py, tools/rocprof_summary.py) and
+    are only quoted here when it equals this tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'text2human_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(csrc, f), 'rb').read())
+    h.update(open(os.path.join(ROOT, 'include', 't2h_hip.h'), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def profile_side_data(kernel_label, config):
+    """What HIP events cannot give: HBM-side bytes per launch and matrix-pipe busy fraction of the
+    dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate
+    passes of this same bench command, gfx950 FETCH x2 correction, tools/pmc_summary.py) and its
+    average duration by rocprofv3 --kernel-trace (tools/rocprof_summary.py) -- launch-weighted over
+    the kernel's shapes.  Read from the committed round-3 summaries, and ONLY if they were taken
+    from this tree's kernel sources (digest check); otherwise the fields are null."""
+    out = {'traffic': None}
     if not kernel_label.startswith('gemm_split'):
-        return {'traffic': None}
-    rows = [r for r in json.load(open(path)) if r['kernel'].startswith('gemm_split')]
-    if not rows:
-        return {'traffic': None}
-    n = sum(r['launches'] for r in rows)
-    mb = sum(r['traffic_mb'] * r['launches'] for r in rows) / n
-    util = sum(r['mfma_util'] * r['launches'] for r in rows) / n
-    return {'traffic': mb * 1e6, 'traffic_unit': 'bytes/launch', 'mfma_util_pmc': util,
-            'traffic_source': f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'}
+        return out
+    want = kernel_src_digest()
+    tag = '' if config == 'parsing' else f'_{config}'
+    path = os.path.join(ROOT, 'profiles', f'r03_pmc_summary{tag}.json')
+    if os.path.exists(path):
+        d = json.load(open(path))
+        if d.get('kernel_src_sha') == want:
+            rows = [r for r in d['rows'] if r['kernel'].startswith('gemm_split')]
+            n = sum(r['launches'] for r in rows)
+            if n:
+                out.update(traffic=sum(r['traffic_mb'] * r['launches'] for r in rows) / n * 1e6,
+                           traffic_unit='bytes/launch',
+                           mfma_util_pmc=sum(r['mfma_util'] * r['launches'] for r in rows) / n,
+                           traffic_source=f'profiles/{os.path.basename(path)} (rocprofv3 --pmc, separate passes; '
+                                          f'kernel sources {want})')
+        else:
+            out['traffic_note'] = f'profiles/{os.path.basename(path)} is from other kernel sources ({d.get("kernel_src_sha")} != {want})'
+    path = os.path.join(ROOT, 'profiles', f'r03_bench_{config}_kernel_stats.json')
+    if os.path.exists(path):
+        d = json.load(open(path))
+        if d.get('kernel_src_sha') == want:
+            rows = [r for r in d['rows'] if r['kernel'].startswith('gemm_split')]
+            n = sum(r['calls'] for r in rows)
+            if n:
+                out['avg_launch_us_rocprof'] = sum(r['avg_us'] * r['calls'] for r in rows) / n
+                out['rocprof_source'] = f'profiles/{os.path.basename(path)}'
+    return out
 
 
 # --------------------------------------------------------------------------- distributed glue
@@ -258,6 +302,165 @@ class StubModel:
         return None, u8.view(self.batch_size, 1, 1, 3).expand(self.batch_size, 512, 256, 3).contiguous()
 
 
+# --------------------------------------------------------------------------- one configuration
+
+
+def gemm_roofline(prof, config):
+    """`roofline` object of the dominant GEMM instantiation (largest sampled time) from the HIP-event
+    samples of ops.gemm_profile_*."""
+    dom = max(prof.values(), key=lambda r: r['ms'])
+    eq = dom['flops'] / (dom['ms'] * 1e-3) / 1e12  # fp32-equivalent 2*M*N*K per launch / time
+    split = dom['kernel'].startswith('gemm_split')
+    # The split-precision kernel's algorithm is three fp16 x fp16 partial products per fp32 multiply
+    # on v_mfma_f32_32x32x16_f16: its matrix-core roofline is the dense 16-bit peak and its executed
+    # work 3 * 2*M*N*K (`frac`); the reference's own FLOP count against the same peak is `frac_useful`.
+    mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
+    ach = eq * mult
+    r = {
+        'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': peak,
+        'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+        'frac_basis': ('executed matrix instructions: 3 fp16 partial products per fp32 multiply'
+                       if split else 'fp32 matrix instructions = the reference FLOP count'),
+        'frac_useful': eq / peak,
+        'fp32_equivalent_tflops': eq, 'frac_of_fp32_mfma_peak': eq / FP32_MFMA_PEAK_TFLOPS,
+        'launches_sampled': dom['n'], 'avg_launch_us': 1000.0 * dom['ms'] / dom['n'],
+        'avg_launch_us_basis': 'HIP events recorded on the launch stream either side of every 37th launch: the '
+                               'interval runs from the END of the previous kernel to the end of this one, i.e. kernel '
+                               'time + the dependent-launch boundary (~2-3 us); rocprofv3 kernel-trace durations '
+                               '(avg_launch_us_rocprof) exclude the boundary',
+        'flop_per_launch': mult * dom['flops'] / dom['n'],
+        'all_gemm_kernels': {k: {'TFLOP/s': v['flops'] / (v['ms'] * 1e-3) / 1e12, 'n': v['n'],
+                                 'avg_us': 1000.0 * v['ms'] / v['n']} for k, v in prof.items()},
+    }
+    r.update(profile_side_data(dom['kernel'], config))
+    if r.get('avg_launch_us_rocprof'):
+        r['frac_rocprof_kernel_time'] = r['frac'] * r['avg_launch_us'] / r['avg_launch_us_rocprof']
+    return r
+
+
+class ConfigRun:
+    """One BASELINE.json configuration on this rank: model + this rank's shard of the global batch."""
+
+    def __init__(self, config, model, batch, sample_steps, set_seed, stub=False):
+        self.config, self.model, self.batch = config, model, batch
+        self.sample_steps, self.set_seed, self.stub = sample_steps, set_seed, stub
+        self.upscale = config == 'hires'
+
+    def step(self, events=None):
+        """events: list that receives (stage name, start event, end event)."""
+        model, batch = self.model, self.batch
+
+        def mark(name, fn):
+            if events is None or self.stub:
+                return fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            events.append((name, e0, e1))
+            return r
+
+        self.set_seed(2021)
+        if self.config == 'pose':
+            def front():
+                model.feed_data(batch)
+                model.generate_parsing_map()
+            mark('pose_front_end', front)
+
+            def tok():
+                model.generate_quantized_segm()
+                model.generate_texture_map()
+            mark('tokenizer', tok)
+        else:
+            mark('tokenizer', lambda: model.feed_data(batch))
+        top = mark('sampler', lambda: model.sample_fn(temp=1, sample_steps=self.sample_steps))
+        _, u8 = mark('refine_decode', lambda: model.decode_indices(top, want_u8=True, upscale=self.upscale))
+        return top, u8
+
+    def timed(self, steps, warmup, dworld, dev):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides;
+        returns the max-over-ranks time and this rank's stage / GEMM samples."""
+        from text2human_amd import shard
+        sync = (lambda: None) if self.stub else torch.cuda.synchronize
+        for _ in range(warmup):
+            self.step()
+        shard.barrier(dworld)
+        sync()
+        if not self.stub:
+            from text2human_amd import ops
+            ops.gemm_profile_start(every=37)  # HIP-event pairs around a sample of GEMM launches
+        events = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            top, u8 = self.step(events)
+        sync()
+        my_elapsed = time.perf_counter() - t0
+        shard.barrier(dworld)
+        elapsed = shard.max_over_ranks(time.perf_counter() - t0, dworld, dev)
+        prof = {} if self.stub else ops.gemm_profile_stop()
+        stage_ms = {}
+        for name, e0, e1 in events:
+            stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / steps
+        stats = getattr(getattr(self.model, 'sampler_fn', None), 'last_stats', None)
+        return dict(elapsed=elapsed, my_elapsed=my_elapsed, top=top, u8=u8, prof=prof, stage_ms=stage_ms, stats=stats)
+
+
+def stage_view(stage_ms, b, sample_steps, upscale, stats):
+    """Per-stage times (HIP events on the launch stream) with the algorithmic rates of SURVEY.md 8(d)."""
+    st = {k: {'ms_per_step': v} for k, v in stage_ms.items()}
+    if 'sampler' in st:
+        fl = GFLOP_IMAGE['sampler_step'] * sample_steps * b * 1e9
+        t = stage_ms['sampler'] * 1e-3
+        st['sampler'].update(tflops_fp32_equivalent=fl / t / 1e12,
+                             frac_useful_of_16bit_peak=fl / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                             note='reference FLOP count = every (sample, step) pair evaluated, as the reference does')
+        if stats:
+            # the work actually launched: one transformer evaluation per sample and ROUND
+            ex = GFLOP_IMAGE['sampler_step'] * stats['sample_steps_launched'] * 1e9
+            st['sampler'].update(
+                sample_steps_possible=stats['sample_steps_possible'], sample_steps_needed=stats['sample_steps_needed'],
+                sample_steps_evaluated=stats['sample_steps_launched'], rounds=stats['rounds'],
+                ms_per_round=stage_ms['sampler'] / max(1, stats['rounds']),
+                executed_frac_of_16bit_peak=3.0 * ex / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                executed_note='3 fp16 partial products per fp32 multiply over the evaluations launched (a (sample, '
+                              'step) pair that changes no token is not evaluated: its logits are never read)')
+    if 'refine_decode' in st:
+        t = stage_ms['refine_decode'] * 1e-3
+        fl = ((GFLOP_IMAGE['decode_hires'] if upscale else GFLOP_IMAGE['decode']) + GFLOP_IMAGE['refine']) * b * 1e9
+        by = DECODE_BYTES_IMAGE['hires' if upscale else 'parsing'] * b + DECODE_WEIGHT_BYTES
+        split_conv = os.environ.get('T2H_SPLIT_CONV', '1') != '0'
+        st['refine_decode'].update(
+            ms_per_image=1e3 * t / b, tflops=fl / t / 1e12,
+            compute_frac_of_fp32_mfma_peak=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            compute_frac_of_16bit_mfma_peak=(3.0 if split_conv else 1.0) * fl / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            algorithmic_hbm_bytes=by, hbm_frac=by / t / (HBM_PEAK_TBS * 1e12),
+            convs=('2xfp16-split MFMA, three products (t2h_conv_split_f32): executed = 3 x the reference FLOPs'
+                   if split_conv else 'exact-fp32 MFMA'),
+            note='SURVEY.md 8(d) algorithmic FLOPs / bytes (flash-style attention, fused norms).  The stage '
+                 'is matrix-bound: at 100% of the fp32 MFMA peak its HBM fraction would be 6.5%, at 100% of '
+                 'the three-product fp16 rate 35%')
+    if 'pose_front_end' in st:
+        t = stage_ms['pose_front_end'] * 1e-3
+        fl = GFLOP_IMAGE['pose'] * b * 1e9
+        st['pose_front_end'].update(tflops=fl / t / 1e12, compute_frac_of_fp32_mfma_peak=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+    return st
+
+
+def side_config(name, run, steps, warmup, batch_per_gpu, world, dworld, dev):
+    """A further BASELINE.json configuration timed inside the same driver-run command (1 warm-up + 2
+    steps by default): its own value, stages and dominant-kernel roofline."""
+    r = run.timed(steps, warmup, dworld, dev)
+    wl = WORKLOADS[name]
+    out = {'metric': wl['metric'], 'value': batch_per_gpu * world * steps / r['elapsed'], 'unit': 'images/s',
+           'ms_per_step': 1000.0 * r['elapsed'] / steps, 'steps': steps, 'warmup': warmup,
+           'config': {'workload': f'{wl["desc"]}, batch={batch_per_gpu}/GPU, {run.sample_steps} sampling steps ({wl["ref"]})',
+                      'global_batch': batch_per_gpu * world},
+           'stages': stage_view(r['stage_ms'], batch_per_gpu, run.sample_steps, run.upscale, r['stats'])}
+    if r['prof']:
+        out['roofline'] = gemm_roofline(r['prof'], name)
+    return out
+
+
 # --------------------------------------------------------------------------- main
 
 
@@ -287,10 +490,10 @@ def main(argv=None):
     from text2human_amd import shard
     wl = WORKLOADS[args.config]
     batch_per_gpu = args.batch or wl['batch']
-    sync = (lambda: None) if stub else torch.cuda.synchronize
 
     # ---- weights: synthesised ONCE (rank 0) and broadcast, not 8x on the host cores
     t_w0 = time.perf_counter()
+    pose = args.config == 'pose'
     if stub:
         sds = shard.broadcast_state_dicts({'sampler': {'w': torch.arange(6.0).view(2, 3)}} if rank == 0 else None,
                                           dworld, dev)
@@ -300,7 +503,6 @@ def main(argv=None):
     else:
         from text2human_amd import defaults, ops, options, synthetic
         from text2human_amd.models import SampleFromParsingModel, SampleFromPoseModel
-        pose = args.config == 'pose'
         opt = options.dict_to_nonedict(defaults.sample_from_pose() if pose else defaults.sample_from_parsing())
         opt['sample_steps'] = args.sample_steps
         sds = synthetic.make_state_dicts(opt, seed=1234) if rank == 0 else None
@@ -309,71 +511,53 @@ def main(argv=None):
         set_seed = options.set_random_seed
     t_weights = time.perf_counter() - t_w0
 
-    # ---- this rank's shard of the global batch (contiguous split); seed 2021 on
-    # every rank's OWN shard (the oracle of a sharded run is the reference on that shard)
-    lo, hi = shard.shard_range(batch_per_gpu * world, rank, world)
-    if stub:
-        g = torch.Generator().manual_seed(2021)
-        full = dict(segm=torch.rand(batch_per_gpu * world, 1, 8, 4, generator=g))
-    elif args.config == 'pose':
-        full = synthetic.pose_batch(batch_per_gpu * world, seed=2021)
-    else:
-        full = synthetic.parsing_batch(batch_per_gpu * world, seed=2021)
-    batch = {k: (v[lo:hi].to(dev) if torch.is_tensor(v) else v[lo:hi]) for k, v in full.items()}
-    upscale = args.config == 'hires'
-    stage_ms = {}
-
-    def one_step(events=None):
-        """events: list that receives (stage name, start event, end event)."""
-        def mark(name, fn):
-            if events is None or stub:
-                return fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn()
-            e1.record()
-            events.append((name, e0, e1))
-            return r
-
-        set_seed(2021)
-        if args.config == 'pose':
-            def front():
-                model.feed_data(batch)
-                model.generate_parsing_map()
-            mark('pose_front_end', front)
-
-            def tok():
-                model.generate_quantized_segm()
-                model.generate_texture_map()
-            mark('tokenizer', tok)
+    def shard_of(config, per_gpu):
+        """this rank's contiguous slice of the global batch; seed 2021 on every rank's OWN
+        shard (the oracle of a sharded run is the reference on that shard)"""
+        lo, hi = shard.shard_range(per_gpu * world, rank, world)
+        if stub:
+            g = torch.Generator().manual_seed(2021)
+            full = dict(segm=torch.rand(per_gpu * world, 1, 8, 4, generator=g))
+        elif config == 'pose':
+            full = synthetic.pose_batch(per_gpu * world, seed=2021)
         else:
-            mark('tokenizer', lambda: model.feed_data(batch))
-        top = mark('sampler', lambda: model.sample_fn(temp=1, sample_steps=args.sample_steps))
-        _, u8 = mark('refine_decode', lambda: model.decode_indices(top, want_u8=True, upscale=upscale))
-        return top, u8
+            full = synthetic.parsing_batch(per_gpu * world, seed=2021)
+        return {k: (v[lo:hi].to(dev) if torch.is_tensor(v) else v[lo:hi]) for k, v in full.items()}, hi - lo
 
-    for _ in range(args.warmup):
-        one_step()
-    shard.barrier(dworld)
-    sync()
-    if not stub:
-        ops.gemm_profile_start(every=37)  # HIP-event pairs around a sample of GEMM launches
-    events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        top, u8 = one_step(events)
-    sync()
-    my_elapsed = time.perf_counter() - t0
-    shard.barrier(dworld)
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dworld, dev)
-    prof = {} if stub else ops.gemm_profile_stop()
-    hw = (1024, 512) if upscale else (512, 256)
-    assert tuple(u8.shape) == (hi - lo, hw[0], hw[1], 3), tuple(u8.shape)
-    for name, e0, e1 in events:
-        stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / args.steps
-    per_rank_ms = shard.gather_floats(1000.0 * my_elapsed / args.steps, dworld, dev)
+    batch, n_mine = shard_of(args.config, batch_per_gpu)
+    run = ConfigRun(args.config, model, batch, args.sample_steps, set_seed, stub)
+    res = run.timed(args.steps, args.warmup, dworld, dev)
+    elapsed, top, u8 = res['elapsed'], res['top'], res['u8']
+    hw = (1024, 512) if run.upscale else (512, 256)
+    assert tuple(u8.shape) == (n_mine, hw[0], hw[1], 3), tuple(u8.shape)
+    per_rank_ms = shard.gather_floats(1000.0 * res['my_elapsed'] / args.steps, dworld, dev)
     # a checksum of every rank's images reaches rank 0 (the optional image gather of SURVEY 8(e))
     sums = shard.gather_floats(float(u8.to(torch.float64).sum()), dworld, dev)
+
+    # ---- the other BASELINE.json configurations, inside the same (driver-run) command
+    other = {}
+    if not stub and args.config == 'parsing' and not args.no_other_configs and not args.batch:
+        # configs[3]'s per-GPU share (batch 256 over 8 GPUs = 32 per GPU) at every N: at N = 8 its global
+        # batch IS configs[3]; the headline line above keeps configs[1]'s 8 per GPU at every N (weak scaling)
+        b32, _ = shard_of('parsing', 32)
+        other['parsing_b32'] = side_config('parsing_b32', ConfigRun('parsing', model, b32, args.sample_steps, set_seed),
+                                           args.other_steps, 1, 32, world, dworld, dev)
+        if world == 1:
+            other['hires'] = side_config('hires', ConfigRun('hires', model, batch, args.sample_steps, set_seed),
+                                         args.other_steps, 1, batch_per_gpu, 1, 1, dev)
+            # sample_from_pose: the same five checkpoints + the parsing generator's three modules
+            popt = options.dict_to_nonedict(defaults.sample_from_pose())
+            popt['sample_steps'] = args.sample_steps
+            schemas = synthetic.module_schemas(popt)
+            psds = dict(sds)
+            for name in ('shape_embedder', 'shape_encoder', 'shape_decoder'):
+                psds[name] = synthetic.fill(schemas[name], 1234 * 1000 + synthetic._SEEDS[name])
+            pmodel = SampleFromPoseModel(popt, state_dicts=psds)
+            pb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic.pose_batch(32, seed=2021).items()}
+            other['pose'] = side_config('pose', ConfigRun('pose', pmodel, pb, args.sample_steps, set_seed),
+                                        args.other_steps, 1, 32, 1, 1, dev)
+            del pmodel, pb
+            torch.cuda.empty_cache()
 
     if rank != 0:
         if use_dist:
@@ -382,9 +566,7 @@ def main(argv=None):
     n_img = batch_per_gpu * world * args.steps
     split_on = os.environ.get('T2H_SPLIT_GEMM', '1') != '0'
     out = {
-        'metric': ('512x256 images/sec (sample_from_parsing)' if args.config == 'parsing' else
-                   '512x256 images/sec (sample_from_pose)' if args.config == 'pose' else
-                   '1024x512 images/sec (upscaled hierarchy)'),
+        'metric': wl['metric'],
         'value': n_img / elapsed,
         'unit': 'images/s',
         'n_gpus': world,
@@ -395,9 +577,11 @@ def main(argv=None):
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': ('stub' if stub else 'f32' if not split_on else
-                  'f32 (sampler Linears + attention as 2xfp16-split MFMA, 3 partial products, fp32 accumulate: '
-                  '22-bit operands, fp32-class accuracy -- see "parity"; decoder convolutions likewise '
-                  '(t2h_conv_split_f32); tokenizer, index-prediction UNet, parsing generator exact-fp32 MFMA)'),
+                  '2xf16-split operands (22 significant bits), f32 accumulate: sampler Linears + attention and the '
+                  'decoder convolutions as 3 fp16 partial products per multiply on v_mfma_f32_32x32x16_f16 -- '
+                  'fp32-class accuracy, see "parity" and "exact_fp32_path" for the strictly-fp32 number; '
+                  'tokenizer, index-prediction UNet, parsing generator exact-f32 MFMA; GELU by a 3-ulp rational erf, '
+                  'softmax in the base-2 domain'),
         'data': 'synthetic',
         'config': {
             'workload': (f'{wl["desc"]}, batch={batch_per_gpu}/GPU, {args.sample_steps} sampling steps '
@@ -421,96 +605,58 @@ def main(argv=None):
         return
 
     # ---- roofline of the dominant kernel = the GEMM instantiation with the largest sampled time
-    if prof:
-        dom = max(prof.values(), key=lambda r: r['ms'])
-        eq = dom['flops'] / (dom['ms'] * 1e-3) / 1e12  # fp32-equivalent 2*M*N*K per launch / time
-        split = dom['kernel'].startswith('gemm_split')
-        # The split-precision kernel's algorithm is three fp16 x fp16 partial products per fp32
-        # multiply on v_mfma_f32_32x32x16_f16: its matrix-core roofline is the dense 16-bit peak and
-        # its executed work 3 * 2*M*N*K (`frac`); the reference's own FLOP count against the same
-        # peak is `frac_useful`.
-        mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
-        ach = eq * mult
-        out['roofline'] = {
-            'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': peak,
-            'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-            'frac_basis': ('executed matrix instructions: 3 fp16 partial products per fp32 multiply'
-                           if split else 'fp32 matrix instructions = the reference FLOP count'),
-            'frac_useful': eq / peak,
-            'fp32_equivalent_tflops': eq, 'frac_of_fp32_mfma_peak': eq / FP32_MFMA_PEAK_TFLOPS,
-            'launches_sampled': dom['n'], 'avg_launch_us': 1000.0 * dom['ms'] / dom['n'],
-            'flop_per_launch': mult * dom['flops'] / dom['n'],
-            'all_gemm_kernels': {k: {'TFLOP/s': v['flops'] / (v['ms'] * 1e-3) / 1e12, 'n': v['n'],
-                                     'avg_us': 1000.0 * v['ms'] / v['n']} for k, v in prof.items()},
-        }
-        out['roofline'].update(pmc_traffic(dom['kernel']))
+    if res['prof']:
+        out['roofline'] = gemm_roofline(res['prof'], args.config)
     # ---- stage view (HIP events on the launch stream), incl. decode's compute AND HBM fractions
-    if stage_ms:
-        st = {k: {'ms_per_step': v} for k, v in stage_ms.items()}
-        b = batch_per_gpu
-        if 'sampler' in st:
-            fl = GFLOP_IMAGE['sampler_step'] * args.sample_steps * b * 1e9
-            st['sampler'].update(tflops_fp32_equivalent=fl / (stage_ms['sampler'] * 1e-3) / 1e12,
-                                 frac_useful_of_16bit_peak=fl / (stage_ms['sampler'] * 1e-3) / 1e12
-                                 / BF16_MFMA_PEAK_TFLOPS)
-        if 'refine_decode' in st:
-            t = stage_ms['refine_decode'] * 1e-3
-            fl = ((GFLOP_IMAGE['decode_hires'] if upscale else GFLOP_IMAGE['decode']) + GFLOP_IMAGE['refine']) * b * 1e9
-            by = DECODE_BYTES_IMAGE['hires' if upscale else 'parsing'] * b + DECODE_WEIGHT_BYTES
-            split_conv = os.environ.get('T2H_SPLIT_CONV', '1') != '0'
-            st['refine_decode'].update(
-                ms_per_image=1e3 * t / b, tflops=fl / t / 1e12,
-                compute_frac_of_fp32_mfma_peak=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                compute_frac_of_16bit_mfma_peak=(3.0 if split_conv else 1.0) * fl / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                algorithmic_hbm_bytes=by, hbm_frac=by / t / (HBM_PEAK_TBS * 1e12),
-                convs=('2xfp16-split MFMA, three products (t2h_conv_split_f32): executed = 3 x the reference FLOPs'
-                       if split_conv else 'exact-fp32 MFMA'),
-                note='SURVEY.md 8(d) algorithmic FLOPs / bytes (flash-style attention, fused norms).  The stage '
-                     'is matrix-bound: at 100% of the fp32 MFMA peak its HBM fraction would be 6.5%, at 100% of '
-                     'the three-product fp16 rate 35%')
-        if 'pose_front_end' in st:
-            t = stage_ms['pose_front_end'] * 1e-3
-            fl = GFLOP_IMAGE['pose'] * b * 1e9
-            st['pose_front_end'].update(tflops=fl / t / 1e12,
-                                        compute_frac_of_fp32_mfma_peak=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS)
-        out['stages'] = st
+    if res['stage_ms']:
+        out['stages'] = stage_view(res['stage_ms'], batch_per_gpu, args.sample_steps, run.upscale, res['stats'])
     # whole-path arithmetic rate on the reference FLOP count
     per_image = (GFLOP_IMAGE['sampler_step'] * args.sample_steps + GFLOP_IMAGE['tokenizer'] + GFLOP_IMAGE['refine']
-                 + (GFLOP_IMAGE['decode_hires'] if upscale else GFLOP_IMAGE['decode'])
-                 + (GFLOP_IMAGE['pose'] if args.config == 'pose' else 0.0)) / 1e3
+                 + (GFLOP_IMAGE['decode_hires'] if run.upscale else GFLOP_IMAGE['decode'])
+                 + (GFLOP_IMAGE['pose'] if pose else 0.0)) / 1e3
     out['path_tflops'] = per_image * out['value'] / world
+    if other:
+        out['other_configs'] = other
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.sample_steps, args.cpu_sampler_steps, args.cpu_repeats)
     if world == 1 and not args.no_exact_fp32 and split_on:
-        # the same step with the sampler's Linears / attention on the exact-fp32 matrix instructions
-        # (T2H_SPLIT_GEMM=0): timing over >= 3 steps AND the parity of the default path against it
+        # the same step with the sampler's Linears / attention AND the decoders' convolutions on the exact-fp32
+        # matrix instructions (T2H_SPLIT_GEMM=0 + T2H_SPLIT_CONV=0): timing over >= 3 steps, and the parity of
+        # the default path against it -- tokens, bottom indices and the image, each through its own kernels
         from text2human_amd import engine
         fast = model.sampler_fn
         model.sampler_fn = engine.SamplerNet(model.P, model._tf_desc, opt['bert_n_head'], 'tf', split=False)
-        one_step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.exact_steps):
-            top_x, u8_x = one_step()
-        sync()
-        dt = (time.perf_counter() - t1) / args.exact_steps
-        model.sampler_fn = fast
+        model.decoder.use_split = model.bot_decoder_res.use_split = False
+        try:
+            run.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.exact_steps):
+                top_x, u8_x = run.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / args.exact_steps
+            img_x, _, int_x = model.decode_indices(top_x, return_inter=True, upscale=run.upscale)
+            img_sx, _, _ = model.decode_indices(top, return_inter=True, upscale=run.upscale)  # exact decoder, default tokens
+        finally:
+            model.sampler_fn = fast
+            model.decoder.use_split = model.bot_decoder_res.use_split = True
         out['exact_fp32_path'] = {'value': batch_per_gpu / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt,
-                                  'note': 'sampler Linears and attention on v_mfma_f32_32x32x2_f32 (bitwise fp32 '
-                                          f'fma chains); 1 warm-up + {args.exact_steps} timed steps'}
+                                  'note': 'sampler Linears / attention and decoder convolutions on '
+                                          'v_mfma_f32_32x32x2_f32 (bitwise fp32 fma chains); '
+                                          f'1 warm-up + {args.exact_steps} timed steps'}
         ts, tx = torch.stack(top), torch.stack(top_x)
         diff = (u8.to(torch.int16) - u8_x.to(torch.int16)).abs()
         n_tok = int((ts != tx).sum())
-        img_s, _, int_s = model.decode_indices(top, return_inter=True, upscale=upscale)
-        img_x, _, int_x = model.decode_indices(top_x, return_inter=True, upscale=upscale)
+        img_s, _, int_s = model.decode_indices(top, return_inter=True, upscale=run.upscale)
         n_bot = sum(int((a['bot_lists'] != c['bot_lists']).sum()) for a, c in zip(int_s, int_x))
         out['parity'] = {
-            'what': 'default split-precision step vs the exact-fp32 step, same batch, same seed, free-running '
-                    f'({args.sample_steps} steps, B={batch_per_gpu}); oracle-side parity on this configuration: '
-                    'tests/test_gpu_bench_parity.py',
+            'what': 'default step (split-precision sampler + decoder) vs the exact-fp32 step (both on '
+                    f'v_mfma_f32_32x32x2_f32), same batch, same seed, free-running ({args.sample_steps} steps, '
+                    f'B={batch_per_gpu}); oracle-side parity on this configuration: tests/test_gpu_bench_parity.py',
             'tokens_equal': n_tok == 0, 'token_mismatches': n_tok, 'tokens': int((ts >= 0).sum()),
             'bot_indices_equal': n_bot == 0, 'bot_index_mismatches': n_bot,
             'img_max_abs': float((img_s - img_x).abs().max()),
+            'img_max_abs_same_tokens': float((img_s - img_sx).abs().max()),
             'images_u8_equal': bool(int(diff.max()) == 0), 'img_u8_max_abs': int(diff.max()),
             'img_u8_frac_differing': float((diff != 0).float().mean()),
         }

@@ -89,3 +89,105 @@ def test_upscaled_hierarchy_1024x512(model, sds):
     got_bot = inter[0]['bot_lists'].view(18, 1, 32, 16).cpu()
     assert torch.equal(got_bot, torch.stack(bot_idx))
     assert (img.cpu() - ref).abs().max().item() < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# Parity AT THE TIMED SHAPES of the configurations bench.py reports under "other_configs":
+# configs[2] sample_from_pose at batch 32 (M = 16384 rows through every sampler Linear: the
+# 256x128 ping-pong tiles for q|k|v / fc1 / fc2, 128x128 for proj -- another dispatch than the
+# headline's M = 4096) and configs[4]'s per-GPU share, the 1024x512 decode of a batch of 8.
+
+
+def _seed(s):
+    torch.manual_seed(s)
+    torch.cuda.manual_seed_all(s)
+
+
+def test_sample_from_pose_batch_32_teacher_forced(model, sds, opt):
+    """B = 32 through the whole pose path: parsing maps vs the oracle (every differing pixel must be a
+    near-tie of the two best classes), tokenizer and texture map exact, then 32 sampling steps teacher-forced on the oracle's trajectory (method of
+    tests/test_gpu_bench_parity.py: each of the 32 x 512 categorical decisions is taken on the
+    oracle's own partially unmasked state -- the oracle's sampler as eager PyTorch-ROCm fp32 on this GPU,
+    with the torch device generator on both sides)."""
+    from text2human_amd import engine
+    Bp, steps = 32, 32
+    pb = synthetic.pose_batch(Bp, seed=2021)
+    model.feed_data(pb)
+    model.generate_parsing_map()
+    dv = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    with torch.no_grad():   # (convolutional stages: the CPU oracle, exact direct fp32 convolutions)
+        segm_ref, logits = R.parsing_from_pose(pb['densepose'], pb['shape_attr'], sds['shape_embedder'],
+                                               sds['shape_encoder'], sds['shape_decoder'],
+                                               opt['shape_attr_class_num'])
+    bad = model.segm.cpu() != segm_ref
+    t2 = logits.topk(2, dim=1).values
+    margin = (t2[:, 0] - t2[:, 1]).unsqueeze(1)
+    assert (margin[bad] < 1e-4).all(), f'{int(bad.sum())} parsing pixels differ beyond a near-tie'
+    assert bad.float().mean() < 1e-3
+    model.segm = segm_ref.to(DEV)                       # identical upstream for the next stages
+    model.generate_quantized_segm()
+    model.generate_texture_map()
+    with torch.no_grad():
+        tok_ref = R.segm_tokens(segm_ref, sds['segm_encoder'], sds['segm_quant_conv'],
+                                sds['segm_quantizer']['embedding.weight']).view(Bp, -1)
+        mask_ref = R.texture_map(segm_ref, pb['upper_fused_attr'], pb['lower_fused_attr'], pb['outer_fused_attr'])
+    assert torch.equal(model.segm_tokens.cpu(), tok_ref)
+    assert torch.equal(model.texture_mask.cpu(), mask_ref)
+    tok_ref, mask_ref = tok_ref.to(DEV), mask_ref.to(DEV)
+    sd_dev = dv(sds['sampler'])
+    trace = []
+    _seed(2021)
+    with torch.no_grad():
+        ref = R.sample_fn(tok_ref, mask_ref, sd_dev, sample_steps=steps, noise=R.TorchNoise(DEV), trace=trace)
+    trace = {d['t']: d for d in trace}
+    mism = []
+
+    def round_hook(r, st, x_t, out):
+        for b, t in enumerate(st.tolist()):
+            if t == 0:
+                continue
+            want = trace[t]['x_t'][b]
+            for j in (x_t[b] != want).nonzero().flatten().tolist():
+                mism.append((t, b, j, int(x_t[b, j]), int(want[j])))
+            x_t[b].copy_(want)
+
+    _seed(2021)
+    assert model.sampler_fn.split and model.sampler_fn.split_mha
+    tex_tok = model._texture_tokens(model.texture_mask)
+    engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, steps, model.mask_id,
+                         round_hook=round_hook, compact=True)
+    assert len(mism) == 0, f'{len(mism)} of {Bp * 512} decisions differ from the oracle: {mism[:5]}'
+    # free-running
+    _seed(2021)
+    top = torch.stack(model.sample_fn(temp=1, sample_steps=steps))
+    assert torch.equal(top, torch.stack(ref))
+
+
+def test_upscaled_hierarchy_batch_of_8(model, sds):
+    """configs[4]'s per-GPU share: 8 images of 1024x512 through refine + decode (chunks of 2 images, the
+    split-precision convolutions at 512x256x... pixel counts, spatial attention over 2048 / 8192
+    positions).  Bottom indices of all 8 exact; images 0, 3 and 7 (first chunk, a middle chunk, last
+    chunk) against the CPU oracle within the image tolerance."""
+    Bh = 8
+    g = torch.Generator().manual_seed(41)
+    tex = torch.randint(0, 18, (Bh, 512), generator=g)
+    val = torch.randint(0, 1024, (Bh, 512), generator=g)
+    top = [torch.where(tex == h, val, torch.full_like(val, -1)) for h in range(18)]
+    mask = tex.view(Bh, 1, 32, 16).float().repeat_interleave(16, 2).repeat_interleave(16, 3)
+    model.texture_mask, model.batch_size = mask.to(DEV), Bh
+    img, u8, inter = model.decode_indices([t.to(DEV) for t in top], want_u8=True, return_inter=True, upscale=True)
+    assert img.shape == (Bh, 3, 1024, 512) and u8.shape == (Bh, 1024, 512, 3)
+    got_bot = torch.cat([d['bot_lists'].view(18, -1, 32, 16) for d in inter], 1).cpu()
+    up = lambda t: F.interpolate(t, scale_factor=2.0, mode='nearest')
+    pq, bq = sds['top_post_quant_conv'], sds['bot_post_quant_conv']
+    with torch.no_grad():
+        tq = F.conv2d(R.top_codebook_entry(top, mask, sds['top_quantize']), pq['weight'], pq['bias'])
+        bot_idx = R.bot_index_prediction(tq, mask, sds['guidance_encoder'], sds['index_decoder'])
+        assert torch.equal(got_bot, torch.stack(bot_idx))
+        qb = F.conv2d(R.bot_codebook_entry(bot_idx, mask, sds['bot_quantize']), bq['weight'], bq['bias'])
+        for i in (0, 3, 7):
+            bh = R.decoder_res(up(qb[i:i + 1]), sds['bot_decoder_res'])
+            dec = R.decoder(up(tq[i:i + 1]), sds['decoder'], bot_h=bh)
+            ref = ((dec + 1) / 2).clamp(0, 1)
+            err = (img[i:i + 1].cpu() - ref).abs().max().item()
+            assert err < 2e-4, (i, err)

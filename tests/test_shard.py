@@ -64,3 +64,32 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / 'ok').exists()
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(11)
+        src = {'a': {'w': torch.randn(3, 4, generator=g), 'cnt': torch.tensor(2**40 + 12345),
+                     'idx': torch.arange(2**24, 2**24 + 9), 'flag': torch.tensor([True, False, True])},
+               'b': {'h': torch.randn(5, generator=g).half(), 'bf': torch.randn(7, generator=g).bfloat16(),
+                     'd': torch.randn(2, 2, generator=g).double()}}
+        got = shard.broadcast_state_dicts(src if rank == 0 else None, world, torch.device('cpu'))
+        assert list(got) == ['a', 'b'] and list(got['a']) == ['w', 'cnt', 'idx', 'flag']
+        for m in src:
+            for k, v in src[m].items():
+                assert got[m][k].dtype == v.dtype and got[m][k].shape == v.shape and torch.equal(got[m][k], v), (m, k)
+        open(os.path.join(out_dir, f'ok{rank}'), 'w').write('1')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_broadcast_state_dicts_keeps_every_dtype_bit_for_bit(tmp_path):
+    """int64 counters / indices above 2^24, bool, fp16 / bf16 / fp64 entries travel in their own dtype
+    (one flat buffer per dtype), not through fp32."""
+    port = _free_port()
+    mp.spawn(_bcast_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()

@@ -25,11 +25,12 @@ class VQGANStack:
 
     def __init__(self, P, name, desc):
         self.P, self.name, self.desc = P, name, desc
+        self.use_split = True  # False: exact-fp32 convolutions even if split-row weights were packed (A/B, bench parity)
 
     def _ws(self, key, hw, mode='same'):
         """Split-row weights of `key` if the stack was packed with them (weights.add_split_conv_weights)
         and t2h_conv_split_f32 serves the shape, else None (-> exact-fp32 kernel)."""
-        ws = self.P.t.get(key + 's')
+        ws = self.P.t.get(key + 's') if self.use_split else None
         return ws if ws is not None and ops.conv_split_ok(hw, mode) else None
 
     def _gn(self, x, pfx, n_img, hw):

@@ -73,10 +73,11 @@ def gather_floats(value, world, device):
 
 def broadcast_state_dicts(sds, world, device, src=0):
     """Checkpoints are read / synthesised ONCE, on rank `src`, and reach the other ranks of the
-    node as one flat fp32 buffer over RCCL/xGMI ("optional broadcast of repacked
-    weights from rank 0 at init") instead of N processes each re-reading or re-synthesising ~0.9 GB
-    on the host.  `sds`: dict module -> state_dict on `src`, ignored (may be None) elsewhere.
-    Returns the same structure with CPU tensors on every rank."""
+    node over RCCL/xGMI ("optional broadcast of repacked weights from rank 0 at
+    init") instead of N processes each re-reading or re-synthesising ~0.9 GB on the host: one flat
+    buffer PER DTYPE, so integer buffers (BatchNorm counters, indices) and half-precision entries
+    travel in their own type, bit for bit.  `sds`: dict module -> state_dict on `src`, ignored
+    (may be None) elsewhere.  Returns the same structure with CPU tensors on every rank."""
     if world == 1:
         return sds
     import torch.distributed as dist
@@ -87,19 +88,30 @@ def broadcast_state_dicts(sds, world, device, src=0):
     dist.broadcast_object_list(meta, src=src)
     meta = meta[0]
     numel = [int(torch.Size(shape).numel()) for _, _, shape, _ in meta]
-    flat = torch.empty(sum(numel), dtype=torch.float64 if any(d == 'torch.float64' for *_, d in meta)
-                       else torch.float32, device=device)
-    if rank == src:
-        off = 0
-        for (m, k, _, _), n in zip(meta, numel):
-            flat[off:off + n].copy_(sds[m][k].reshape(-1))
-            off += n
-    dist.broadcast(flat, src=src)
+    groups = {}
+    for i, (_, _, _, dtype) in enumerate(meta):
+        groups.setdefault(dtype, []).append(i)
+    out = {}
+    for dtype in sorted(groups):
+        idxs = groups[dtype]
+        td = getattr(torch, dtype.split('.')[-1])
+        wire = torch.uint8 if td == torch.bool else td  # (no bool collectives)
+        flat = torch.empty(sum(numel[i] for i in idxs), dtype=wire, device=device)
+        if rank == src:
+            off = 0
+            for i in idxs:
+                m, k = meta[i][0], meta[i][1]
+                flat[off:off + numel[i]].copy_(sds[m][k].reshape(-1).to(wire))
+                off += numel[i]
+        dist.broadcast(flat, src=src)
+        if rank == src:
+            continue
+        host, off = flat.cpu(), 0
+        for i in idxs:
+            m, k, shape, _ = meta[i]
+            out.setdefault(m, {})[k] = host[off:off + numel[i]].view(shape).to(td)
+            off += numel[i]
     if rank == src:
         return sds
-    host = flat.cpu()
-    out, off = {}, 0
-    for (m, k, shape, dtype), n in zip(meta, numel):
-        out.setdefault(m, {})[k] = host[off:off + n].view(shape).to(getattr(torch, dtype.split('.')[-1]))
-        off += n
-    return out
+    # module / key order of the source (state_dict order matters to strict loaders)
+    return {m: {k: out[m][k] for mm, k, _, _ in meta if mm == m} for m in dict.fromkeys(mm for mm, *_ in meta)}

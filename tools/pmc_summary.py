@@ -5,12 +5,20 @@ on gfx950 FETCH_SIZE reports 1/2 of a wide (16 B/lane) coalesced read stream
 -> read bytes = 2 * FETCH_SIZE * 1024 (WRITE_SIZE checked exact against the
 known output bytes of the GEMMs: 4096x2048x4 B = 32768 KiB).
 
-    python tools/pmc_summary.py gpurun_out profiles/r01_pmc_summary
+    python tools/pmc_summary.py gpurun_out profiles/r03_pmc_summary ["bench.py arguments of the passes"]
+
+The JSON carries the digest of the kernel sources it was measured on (bench.kernel_src_digest) and
+the git HEAD; bench.py quotes it only while that digest equals the tree's.
 """
 import json
+import os
 import re
 import sqlite3
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def short(name):
@@ -30,7 +38,7 @@ def load(db, counters):
     return out
 
 
-def main(root, out_prefix):
+def main(root, out_prefix, what='bench.py --steps 1 --warmup 1'):
     f = load(f'{root}/pmc_FETCH_SIZE/p_results.db', {'FETCH_SIZE'})
     w = load(f'{root}/pmc_WRITE_SIZE/p_results.db', {'WRITE_SIZE'})
     m = load(f'{root}/pmc_SQ_VALU_MFMA_BUSY_CYCLES/p_results.db',
@@ -45,8 +53,11 @@ def main(root, out_prefix):
                          traffic_mb=(2 * fetch + wr) * 1024 / 1e6, mfma_util=util, total_us=n * us))
     rows.sort(key=lambda r: -r['total_us'])
     rows = rows[:24]
-    json.dump(rows, open(out_prefix + '.json', 'w'), indent=1)
-    lines = ['# rocprofv3 --pmc summary (separate passes; bench.py --sample-steps 4)', '',
+    import bench
+    head = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+    sha = bench.kernel_src_digest()
+    json.dump(dict(kernel_src_sha=sha, git_head=head, command=what, rows=rows), open(out_prefix + '.json', 'w'), indent=1)
+    lines = [f'# rocprofv3 --pmc summary (separate passes; {what}; kernel sources {sha}, HEAD {head or "n/a"})', '',
              'traffic MB = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH correction); '
              'mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)', '',
              '| kernel | grid threads | launches | avg us | FETCH KiB | WRITE KiB | traffic MB | MFMA util |',
@@ -59,4 +70,4 @@ def main(root, out_prefix):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

@@ -1,10 +1,19 @@
 """Condenses a rocprofv3 (rocpd sqlite) result into a small per-kernel table.
 
-    python tools/rocprof_summary.py gpurun_out/prof2/r2_results.db profiles/r01_bench_kernel_stats.md
+    python tools/rocprof_summary.py gpurun_out/prof2/r2_results.db profiles/r03_bench_parsing_kernel_stats.md
+
+Writes the .md table and, beside it, a .json with the same rows plus the digest of the kernel sources
+(bench.kernel_src_digest) and the git HEAD, which bench.py checks before quoting a duration.
 """
+import json
+import os
 import re
 import sqlite3
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def short(name):
@@ -36,8 +45,16 @@ def main(db_path, out_path):
     for k, (n, tot, mn, mx, vg, ag, lds) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append(f'| `{k}` | {n} | {tot / 1e6:.2f} | {tot / n / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | '
                      f'{100 * tot / total:.2f} | {vg} | {ag} | {lds} |')
-    hdr = f'# rocprofv3 --kernel-trace --stats summary\n\nsource: `{db_path}`; total kernel time {total / 1e6:.1f} ms\n\n'
+    import bench
+    head = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+    sha = bench.kernel_src_digest()
+    hdr = (f'# rocprofv3 --kernel-trace --stats summary\n\nsource: `{db_path}`; total kernel time {total / 1e6:.1f} ms; '
+           f'kernel sources {sha}, HEAD {head or "n/a"}\n\n')
     open(out_path, 'w').write(hdr + '\n'.join(lines) + '\n')
+    rows_j = [dict(kernel=k, calls=n, total_ms=tot / 1e6, avg_us=tot / n / 1e3, min_us=mn / 1e3, max_us=mx / 1e3)
+              for k, (n, tot, mn, mx, vg, ag, lds) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+    json.dump(dict(kernel_src_sha=sha, git_head=head, total_kernel_ms=total / 1e6, rows=rows_j),
+              open(os.path.splitext(out_path)[0] + '.json', 'w'), indent=1)
     print('\n'.join(lines[:14]))
 
 
