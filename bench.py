@@ -54,6 +54,10 @@ HBM_PEAK_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec
 # algorithmic work per image (exact, 2 * MAC) and algorithmic HBM bytes
 GFLOP_IMAGE = dict(sampler_step=99.858, tokenizer=40.49, refine=2.19, decode=562.88, pose=239.86,
                    decode_hires=2380.0)
+# of the 99.858 GFLOP of one reference sampler evaluation 9.664 are the 18 full [512, 1024] head
+# projections (models/archs/transformer_arch.py:271); the HIP path runs the head of a token's own
+# texture for the changed tokens only, so the work it EXECUTES per evaluation is the 24 layers
+GFLOP_SAMPLER_LAYERS = 99.858 - 18 * 2 * 512 * 1024 * 512 / 1e9
 DECODE_BYTES_IMAGE = dict(parsing=1.870e9, hires=7.48e9)
 DECODE_WEIGHT_BYTES = 216.5e6
 WORKLOADS = {
@@ -416,14 +420,16 @@ def stage_view(stage_ms, b, sample_steps, upscale, stats):
                              note='reference FLOP count = every (sample, step) pair evaluated, as the reference does')
         if stats:
             # the work actually launched: one transformer evaluation per sample and ROUND
-            ex = GFLOP_IMAGE['sampler_step'] * stats['sample_steps_launched'] * 1e9
+            ex = GFLOP_SAMPLER_LAYERS * stats['sample_steps_launched'] * 1e9
             st['sampler'].update(
                 sample_steps_possible=stats['sample_steps_possible'], sample_steps_needed=stats['sample_steps_needed'],
                 sample_steps_evaluated=stats['sample_steps_launched'], rounds=stats['rounds'],
                 ms_per_round=stage_ms['sampler'] / max(1, stats['rounds']),
                 executed_frac_of_16bit_peak=3.0 * ex / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                executed_note='3 fp16 partial products per fp32 multiply over the evaluations launched (a (sample, '
-                              'step) pair that changes no token is not evaluated: its logits are never read)')
+                executed_note='3 fp16 partial products per fp32 multiply over the 24 layers (90.19 GFLOP fp32-equivalent) '
+                              'of the evaluations launched; a (sample, step) pair that changes no token is not '
+                              'evaluated (its logits are never read), and of the 18 head projections only the rows '
+                              'that are sampled are computed')
     if 'refine_decode' in st:
         t = stage_ms['refine_decode'] * 1e-3
         fl = ((GFLOP_IMAGE['decode_hires'] if upscale else GFLOP_IMAGE['decode']) + GFLOP_IMAGE['refine']) * b * 1e9
