@@ -120,7 +120,8 @@ int t2h_gn_apply_split_f32(const float* x, int32_t ldx, const float* scale, cons
  * by t2h_split_rows_f32 / the C_split epilogue.
  * Replaces the same nn.Linear call sites as t2h_gemm_f32 (default path of the sampler).
  * Dispatch (automatic; t2h_gemm_split_force_config overrides): 256x128 tiles with a ping-pong LDS-DMA
- * loop when they give >= 192 tiles, 128x64 with an in-block K split when N = 512 at M = 4096, a
+ * loop when they give >= 192 tiles (128x192 on the same loop where that takes fewer rounds of the 256
+ * CUs: q|k|v at M = 4096), 128x64 with an in-block K split when N = 512 at M = 4096, a
  * few-rows kernel (16x16x32 MFMA straight from global memory, K split over 8 waves) for M <= 64,
  * 128x64 / 128x128 otherwise.  Operands must span < 2 GiB each (32-bit byte offsets). */
 typedef struct t2h_gemm_split_args {
@@ -153,7 +154,7 @@ int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
  * last reset, 0 if not, < 0 on error; reset != 0 clears it.  The host side clears it at the start of a
  * sampling run / decode and checks it at the end. */
 int t2h_split_overflow(int32_t reset, void* stream);
-int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..3, 5, 6, 8 (ping-pong LDS-DMA), 9 (few-rows kernel), -1 auto;
+int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..3, 5, 6, 8 / 10 (ping-pong LDS-DMA, 256x128 / 128x192), 9 (few-rows kernel), -1 auto;
                                               thread-local: it affects launches of the calling thread only */
 /* fp32 [rows, C] (row stride ldx) -> split rows */
 int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);

@@ -180,7 +180,7 @@ def test_stale_overflow_flag_is_not_this_runs_and_decode_checks_its_own(opt, sds
     assert not ops.split_overflow(reset=False)
     model.decode_indices(top)
     bad = {k: dict(v) for k, v in sds.items()}
-    bad['top_post_quant_conv']['weight'] = sds['top_post_quant_conv']['weight'] * 1.0e7
+    bad['top_post_quant_conv']['weight'] = sds['top_post_quant_conv']['weight'] * 1.0e12
     m2 = SampleFromParsingModel(opt, state_dicts=bad)
     m2.feed_data(synthetic.parsing_batch(1, seed=33))
     with pytest.raises(engine.SplitOverflowError, match='VQGAN refine / decode.*T2H_SPLIT_CONV'):

@@ -30,7 +30,7 @@ def test_split_rows_carry_22_bits_and_match_the_host_pack():
     assert ((back - x).abs() <= x.abs() * 2.0**-21 + 2.0**-36).all()
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 5, 6, 8, 9])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 5, 6, 8, 9, 10])
 @pytest.mark.parametrize('M,N,K', [(4096, 512, 512), (1024, 1536, 512), (512, 512, 2048), (130, 96, 64),
                                    (40, 32, 32)])
 def test_gemm_split(cfg, M, N, K):
@@ -96,7 +96,7 @@ def _pack_vt_host(v, B, T, H):
     return out.view(torch.int16)
 
 
-@pytest.mark.parametrize('cfg', [0, 2, 3, 6, 8])
+@pytest.mark.parametrize('cfg', [-1, 0, 2, 3, 6, 8, 10])
 def test_gemm_split_routes_value_columns_to_transposed_planes(cfg):
     B, T, H, C = 2, 512, 8, 512
     M = B * T

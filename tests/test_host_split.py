@@ -1,5 +1,6 @@
 """Host-side pieces of the split-precision path (CPU): the two-plane fp16 representation,
 its row layout, and the key order of the transposed value planes."""
+import pytest
 import torch
 
 from text2human_amd import ops
@@ -116,10 +117,12 @@ def test_lds_dma_swizzle_algebra_of_the_attention_kernel():
                     _conflict_free(addr)
 
 
-def test_lds_dma_swizzle_algebra_of_the_gemm_tile_image():
+@pytest.mark.parametrize('BM,BN,WM,WN', [(256, 128, 64, 64), (128, 192, 32, 96)])
+def test_lds_dma_swizzle_algebra_of_the_gemm_tile_image(BM, BN, WM, WN):
     """gemm_split_kernel<.., PP = 2> (csrc/gemm_split.hip): 8-row groups of 128-byte rows, logical piece
-    c of row r at c ^ ((r >> 1) & 7); fragment piece = plane * 4 + u * 2 + (lane >> 5)."""
-    rows = 384                                   # 256 A rows + 128 B rows of a K tile
+    c of row r at c ^ ((r >> 1) & 7); fragment piece = plane * 4 + u * 2 + (lane >> 5).  Both tile
+    shapes of the loop: 256x128 (wave tile 64x64) and 128x192 (wave tile 32x96)."""
+    rows = BM + BN                               # A rows + B rows of a K tile
     slot = {}
     for wave in range(8):
         for i in range(rows // 64):
@@ -128,8 +131,12 @@ def test_lds_dma_swizzle_algebra_of_the_gemm_tile_image():
                 r = g * 8 + (lane >> 3)
                 pc = (lane & 7) ^ ((r >> 1) & 7)                          # source piece
                 slot[(g * 1024 + lane * 16) // 16] = (r, pc)
+                assert (r < BM) == (i < BM // 64)                         # one operand per DMA round i
     assert len(slot) == rows * 8
-    for row0 in (0, 64, 256, 320):               # wave-tile row offsets (multiples of 16)
+    frag_rows = [wm0 + ti * 32 for wm0 in range(0, BM, WM) for ti in range(WM // 32)]
+    frag_rows += [BM + wn0 + tj * 32 for wn0 in range(0, BN, WN) for tj in range(WN // 32)]
+    assert sorted(frag_rows) == list(range(0, rows, 32))
+    for row0 in frag_rows:                       # MFMA-tile row offsets (multiples of 32)
         for c2 in range(4):                      # c2 = plane * 2 + u
             addr = lambda lane: (row0 + (lane & 31)) * 128 + (((c2 * 2 + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) * 16)
             for lane in range(64):

@@ -488,7 +488,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   auto fin = [&](int ti, int tj, int r, float bv) {
     return fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]) + bv;
   };
-  if (p.Vt != nullptr && n0 >= p.vt_col0) {
+  // A tile whose columns straddle vt_col0 (BN = 192 does not divide the q|k / v boundary at 1024) takes
+  // both forms of the epilogue, each skipping the other side's columns; tiles of the other shapes lie on
+  // one side (the host checks vt_col0 % BN == 0) and keep the single pass.
+  constexpr bool MIXED = BN % 128 != 0;
+  const bool all_v = p.Vt != nullptr && n0 >= p.vt_col0;
+  const bool some_v = MIXED ? (p.Vt != nullptr && n0 + BN > p.vt_col0) : all_v;
+  if (some_v) {
     // Value heads of the q|k|v projection -> transposed planes Vt[B][H][2][hd][T].  The wave
     // tile is staged TRANSPOSED ([column][row]: a lane's 4 consecutive accumulator registers
     // are 4 consecutive rows = one 16-byte LDS write), then every lane takes one column and
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       const int cl = c / RG, u = c - cl * RG;
       const int col = n0 + wn0 + cl;
       const int ra = 16 * (u >> 1) + 4 * (u & 1);  // rows ra..ra+3 and ra+8..ra+11
-      if (row0 + ra >= p.M || col >= p.N) continue;
+      if (row0 + ra >= p.M || col >= p.N || (MIXED && col < p.vt_col0)) continue;
       f32x4 va = *reinterpret_cast<const f32x4*>(Ot + cl * OT_LD + ra);
       f32x4 vb = *reinterpret_cast<const f32x4*>(Ot + cl * OT_LD + ra + 8);
       if (KS == 2) {
@@ -547,7 +553,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       t2h_store16_wt(dstp, vh);
       t2h_store16_wt(dstp + (int64_t)p.vt_hd * p.vt_T, vl);
     }
-    return;
+    if (!MIXED || all_v) return;
+    __syncthreads();  // the staging area is rewritten row-major below
   }
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti) {
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     const int c = lane + 64 * (it + kg * NCH);
     const int rl = c / CPR, c8 = (c - rl * CPR) * 8;
     const int row = m0 + wm0 + rl, col = n0 + wn0 + c8;
-    const bool valid = row < p.M && col < p.N;
+    const bool valid = row < p.M && col < p.N && !(MIXED && some_v && col >= p.vt_col0);
     if (!valid) continue;
     f32x4 va = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8);
     f32x4 vb = *reinterpret_cast<const f32x4*>(Ot + rl * O_LD + c8 + 4);
@@ -666,8 +673,8 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1, int PP = 0>
 int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE(a.K % (32 * KS) == 0, "t2h_gemm_split_f32: this tile config needs K %% %d == 0", 32 * KS);
   if (a.Vt)
-    T2H_REQUIRE(a.vt_col0 % BN == 0, "t2h_gemm_split_f32: vt_col0=%d must be a multiple of the %d-column tile",
-                a.vt_col0, BN);
+    T2H_REQUIRE(a.vt_col0 % (BN % 128 ? 32 : BN) == 0, "t2h_gemm_split_f32: vt_col0=%d must be a multiple of %d for this tile",
+                a.vt_col0, BN % 128 ? 32 : BN);
   T2H_REQUIRE((int64_t)(a.M > a.N ? a.M : a.N) * a.K * 4 < (int64_t(1) << 31),
               "t2h_gemm_split_f32: operands are addressed with 32-bit byte offsets (each must span < 2 GiB)");
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
@@ -729,6 +736,13 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
       // 128x128 tiles, fc2 93 vs 111), on the ping-pong LDS-DMA loop (5-6 % faster than the same tile
       // on the register-staged loop, the twin round 2 kept for the A/B and round 3 removed)
       cfg = 8;
+      // 128x192 tiles (the same loop, wave tile 32x96) where they need fewer tile-rounds of the chip's 256
+      // CUs: q|k|v at M = 4096 is 192 tiles of 256x128 -- a quarter of the CUs idle for the whole launch --
+      // or 256 tiles of 128x192, one per CU with 3/4 of the work each
+      if (a.M % 128 == 0 && a.N % 192 == 0 && (a.Vt == nullptr || a.vt_col0 % 32 == 0)) {
+        const int64_t t192 = (int64_t)(a.M / 128) * (a.N / 192);
+        if (((t192 + 255) / 256) * (128 * 192) < ((tiles_big + 255) / 256) * (256 * 128)) cfg = 10;
+      }
     else if (tiles128 >= 1024) cfg = 1;
     else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
     else cfg = 0;
@@ -750,6 +764,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
     case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
     case 8: return launch_split<256, 128, 4, 2, 1, 2>(a, s);  // 8 waves, wave tile 64x64, ping-pong LDS-DMA loop
+    case 10: return launch_split<128, 192, 4, 2, 1, 2>(a, s);  // 8 waves, wave tile 32x96, the same loop
     default: return launch_split<128, 64, 2, 2>(a, s);  // 4 waves, wave tile 64x32
   }
 }
