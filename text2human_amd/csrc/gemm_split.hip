@@ -326,6 +326,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       if (grp == 1) wait_landed();  // tile kt + 1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       pp_barrier();
+      // (round 3 tried issuing the requests for tile kt + 2 here instead, one after every fourth matrix
+      // instruction: q|k|v 26.4 vs 26.9 us, fc1 30.7 vs 30.6, K = 2048 shapes 10 % slower -- not the
+      // request issue cost either; removed.  profiles/r03_gemm_tile_and_dma_placement.log)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -730,7 +733,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     const int64_t tiles256 = (int64_t)((a.M + 127) / 128) * ((a.N + 255) / 256);
     const int64_t tiles_big = (a.M % 256 == 0 && a.N % 128 == 0) ? (int64_t)(a.M / 256) * (a.N / 128) : 0;
     if (a.M <= 64) cfg = 2;
-    else if (tiles_big >= 192)
+    else if (tiles_big >= 192) {
       // 256x128 tiles wherever they give (nearly) every CU one: q|k|v / fc1 at M = 4096 (192 / 256
       // tiles) and every sampler Linear but proj at M = 16384 (q|k|v 99 vs 104 / 126 us for the 128x64 /
       // 128x128 tiles, fc2 93 vs 111), on the ping-pong LDS-DMA loop (5-6 % faster than the same tile
@@ -743,7 +746,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
         const int64_t t192 = (int64_t)(a.M / 128) * (a.N / 192);
         if (((t192 + 255) / 256) * (128 * 192) < ((tiles_big + 255) / 256) * (256 * 128)) cfg = 10;
       }
-    else if (tiles128 >= 1024) cfg = 1;
+    } else if (tiles128 >= 1024) cfg = 1;
     else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
     else cfg = 0;
   }
