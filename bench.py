@@ -93,6 +93,7 @@ def parse_args(argv=None):
     ap.add_argument('--exact-steps', type=int, default=3)
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the "other_configs" legs (configs[3] per-GPU share, pose B=32, hires B=8) of the default run')
+    ap.add_argument('--no-graph-leg', action='store_true', help='skip the T2H_GRAPH=1 (graph replay) timing leg')
     ap.add_argument('--other-steps', type=int, default=2, help='timed steps of each other_configs leg (after 1 warm-up)')
     ap.add_argument('--eager-gpu-baseline', action='store_true',
                     help='also time the oracle sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
@@ -666,6 +667,24 @@ def main(argv=None):
             'images_u8_equal': bool(int(diff.max()) == 0), 'img_u8_max_abs': int(diff.max()),
             'img_u8_frac_differing': float((diff != 0).float().mean()),
         }
+    if world == 1 and not args.no_graph_leg:
+        # the same step with every sampling round replayed from ONE captured hipGraph (T2H_GRAPH=1) instead of
+        # ~180 launches per round from the host thread: same kernels, same tokens (tests/test_gpu_edge_cases.py)
+        os.environ['T2H_GRAPH'] = '1'
+        try:
+            run.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.other_steps):
+                top_g, u8_g = run.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / args.other_steps
+        finally:
+            os.environ.pop('T2H_GRAPH', None)
+        out['graph_replay'] = {'value': batch_per_gpu / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt,
+                               'tokens_equal': bool(torch.equal(torch.stack(top_g), torch.stack(top))),
+                               'images_u8_equal': bool(torch.equal(u8_g, u8)),
+                               'note': f'T2H_GRAPH=1 (opt-in), 1 capture / warm-up step + {args.other_steps} timed steps'}
     if world == 1 and args.eager_gpu_baseline:
         out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, 16, dev)
     print(json.dumps(out), flush=True)

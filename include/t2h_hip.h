@@ -265,6 +265,8 @@ typedef struct t2h_sample_heads_args {
   const uint64_t* row_philox_offset;
   const float* expo_rows;
   const int32_t* expo_slot;
+  const uint64_t* philox_seed_dev; /* if set, the seed is read from device memory (a captured launch sequence
+                                      replayed for runs with different seeds); else philox_seed */
 } t2h_sample_heads_args;
 /* dst[i] = src[rows[i]], rows of row_bytes (multiple of 16) bytes */
 int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, int32_t n_rows, int32_t row_bytes, void* stream);
@@ -290,6 +292,15 @@ int t2h_philox_uniform_f32(uint64_t seed, uint64_t offset, uint32_t grid_threads
 int t2h_unmask_schedule(uint64_t seed, uint64_t offset, uint32_t rand_grid_threads, uint32_t rand_inc,
                         uint32_t expo_inc, const int64_t* tex, int32_t n, int32_t steps, int32_t n_heads,
                         int32_t* step_of_row, uint32_t* head_mask, void* stream);
+/* Round cursor of a schedule laid out as padded tables [rounds][maxr] (a round's list padded with
+ * copies of one of its own rows: sampling a row twice writes the same token twice): copies round
+ * r = *round_ctr of rows_tbl (and of aux64_tbl = per-row generator offsets / aux32_tbl = per-row explicit
+ * noise slots, either may be NULL) into cur_rows / cur_aux64 / cur_aux32 and sets *round_ctr = r + 1.
+ * With it one round of engine.sample_tokens is a fixed launch sequence with fixed arguments -- a
+ * hipGraph captured once and replayed per round. */
+int t2h_schedule_advance(const int32_t* rows_tbl, const int64_t* aux64_tbl, const int32_t* aux32_tbl,
+                         int32_t* round_ctr, int32_t* cur_rows, int64_t* cur_aux64, int32_t* cur_aux32,
+                         int32_t maxr, void* stream);
 int t2h_sample_heads(const t2h_sample_heads_args* args, void* stream);
 
 /* Sampler training-time forward (models/transformer_model.py:212-274, forward only).

@@ -57,7 +57,7 @@ class SampleHeadsArgs(ctypes.Structure):
         ('logits_ws', c_vp), ('hidden_compact', c_i32),
         ('philox_seed', ctypes.c_uint64), ('philox_offset', ctypes.c_uint64 * MAX_HEADS),
         ('philox_grid_threads', ctypes.c_uint32),
-        ('row_philox_offset', c_vp), ('expo_rows', c_vp), ('expo_slot', c_vp),
+        ('row_philox_offset', c_vp), ('expo_rows', c_vp), ('expo_slot', c_vp), ('philox_seed_dev', c_vp),
     ]
 
 
@@ -93,6 +93,7 @@ SIGNATURES = {
     't2h_philox_uniform_f32': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, c_vp, c_i64, c_vp]),
     't2h_unmask_schedule': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                            ctypes.c_uint32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    't2h_schedule_advance': (ctypes.c_int, [c_vp] * 7 + [c_i32, c_vp]),
     't2h_q_sample': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp]),
     't2h_masked_ce_heads': (ctypes.c_int, [c_vp] * 9 + [c_i32] * 5 + [c_vp]),
     't2h_sample_head': (ctypes.c_int, [c_vp] * 7 + [c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

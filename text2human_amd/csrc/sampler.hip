@@ -399,6 +399,25 @@ __global__ __launch_bounds__(SCHED_THREADS) void unmask_schedule_kernel(
   for (int t = tid; t <= steps; t += SCHED_THREADS) head_mask[t] = mask_s[t];
 }
 
+// ---- round cursor of a pre-computed schedule (engine.sample_tokens, graph replay): copies round
+// r = *round_ctr of the padded [rounds][maxr] tables into fixed staging buffers and advances the
+// counter, so that every round of a sampling run is the SAME launch sequence with the same arguments
+// (capturable once, replayed per round) while the rows / generator offsets it works on change.
+__global__ void schedule_advance_kernel(const int32_t* __restrict__ rows_tbl, const int64_t* __restrict__ aux64_tbl,
+                                        const int32_t* __restrict__ aux32_tbl, int32_t* __restrict__ round_ctr,
+                                        int32_t* __restrict__ cur_rows, int64_t* __restrict__ cur_aux64,
+                                        int32_t* __restrict__ cur_aux32, int maxr) {
+  const int r = *round_ctr;
+  for (int i = threadIdx.x; i < maxr; i += blockDim.x) {
+    const int64_t j = (int64_t)r * maxr + i;
+    cur_rows[i] = rows_tbl[j];
+    if (aux64_tbl) cur_aux64[i] = aux64_tbl[j];
+    if (aux32_tbl) cur_aux32[i] = aux32_tbl[j];
+  }
+  __syncthreads();  // every thread has read r
+  if (threadIdx.x == 0) *round_ctr = r + 1;
+}
+
 // ---- two-launch form of the same tail (t2h_sample_heads with a logits workspace).  One workgroup
 // per changed row streams 2 MB of head weights by itself (~50 us per step with ~16 rows on 16 CUs);
 // here SL_SPLIT workgroups per row take n_class / SL_SPLIT classes each (LN_f recomputed per
@@ -488,11 +507,12 @@ __global__ __launch_bounds__(SH_THREADS) void sample_pick_kernel(const t2h_sampl
                     : a.philox_grid_threads ? nullptr
                                             : a.expo[head] + (int64_t)row * a.n_class;
   const uint64_t poff = a.row_philox_offset ? a.row_philox_offset[slot] : a.philox_offset[head];
+  const uint64_t pseed = a.philox_seed_dev ? *a.philox_seed_dev : a.philox_seed;
   float best = -1.f;
   int best_j = 0x7fffffff;
   for (int j = tid; j < a.n_class; j += SH_THREADS) {
     const float q = er ? er[j]
-                       : torch_exponential_at(a.philox_seed, poff, a.philox_grid_threads,
+                       : torch_exponential_at(pseed, poff, a.philox_grid_threads,
                                               (uint64_t)row * a.n_class + j);
     const float sc = expf(lg[j] - mx) / q;
     if (sc > best) {
@@ -642,6 +662,17 @@ extern "C" int t2h_masked_ce_heads(const float* hidden, const float* lnf_gamma, 
                      w_heads, tex, mask, gt_lists, ce_rows, B * T, n_class, n_heads);
   hipLaunchKernelGGL(segment_sum_kernel, dim3(B), dim3(256), 0, s, ce_rows, ce_samples, T);
   T2H_CHECK_LAUNCH("t2h_masked_ce_heads");
+  return T2H_OK;
+}
+
+extern "C" int t2h_schedule_advance(const int32_t* rows_tbl, const int64_t* aux64_tbl, const int32_t* aux32_tbl,
+                                    int32_t* round_ctr, int32_t* cur_rows, int64_t* cur_aux64, int32_t* cur_aux32,
+                                    int32_t maxr, void* stream) {
+  T2H_REQUIRE(rows_tbl && round_ctr && cur_rows && maxr > 0 && (!aux64_tbl || cur_aux64) && (!aux32_tbl || cur_aux32),
+              "t2h_schedule_advance: bad arguments");
+  hipLaunchKernelGGL(schedule_advance_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), rows_tbl,
+                     aux64_tbl, aux32_tbl, round_ctr, cur_rows, cur_aux64, cur_aux32, maxr);
+  T2H_CHECK_LAUNCH("t2h_schedule_advance");
   return T2H_OK;
 }
 

@@ -168,11 +168,13 @@ class SamplerNet:
         # projection writes q, k as split rows and v as transposed planes, no fp32 qkv
         self.split_mha = split_mha
         self._buf = {}
+        self._graphs = {}       # captured sampling rounds (RoundGraph), see sample_tokens
         self.last_stats = None  # schedule.stats of the last sample_tokens run
 
     def _buffers(self, M, C, dev):
         key = (M, C, str(dev))
         if key not in self._buf:
+            self._graphs = {}  # captured rounds hold pointers into the buffers replaced below
             e = lambda n: torch.empty((M, n), device=dev, dtype=torch.float32)
             R = self.TRIM_MAX_ROWS
             self._buf = {key: dict(x=e(C), h=e(C), qkv=e(3 * C), y=e(C), u=e(4 * C),
@@ -355,8 +357,10 @@ class SampleSchedule:
     """Device-resident schedule of one sample_tokens run (see schedule.py): rows of round r =
     rows[start[r]:start[r + 1]], each with its own noise reference."""
 
-    def __init__(self, rows, start, round_steps, noise_kind, seed=None, offsets=None, expo_rows=None, slots=None):
+    def __init__(self, rows, start, round_steps, noise_kind, seed=None, offsets=None, expo_rows=None, slots=None,
+                 host=None):
         self.rows, self.start, self.round_steps = rows, start, round_steps
+        self.host = host  # (row order, per-row offsets) as numpy, for the padded tables of the graph path
         self.noise_kind, self.seed, self.offsets, self.expo_rows, self.slots = noise_kind, seed, offsets, expo_rows, slots
         self.n_rounds = len(start) - 1
         self.max_rows = int(max(int(start[r + 1] - start[r]) for r in range(self.n_rounds))) if self.n_rounds else 0
@@ -388,7 +392,7 @@ def build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact=True)
         offs = expo_off[step_of_row[order], tex_host[order]]
         assert (offs >= 0).all()
         return SampleSchedule(torch.from_numpy(order.astype(np.int32)).to(dev), start, round_steps, 'philox', seed=seed,
-                              offsets=torch.from_numpy(offs).to(dev))
+                              offsets=torch.from_numpy(offs).to(dev), host=(order, offs))
     # explicit draws (tests replaying CPU noise; the emulation fallback): the reference's own loop
     # order, with the rows each head needs copied out of its full draw
     unmasked = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -418,6 +422,75 @@ def build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact=True)
     order, start, round_steps = schedule.group_rounds(step_of_row, B, T, compact)
     return SampleSchedule(torch.from_numpy(order.astype(np.int32)).to(dev), start, round_steps, 'explicit',
                           expo_rows=expo_rows, slots=torch.from_numpy(slot_of_row[order]).to(dev))
+
+
+class RoundGraph:
+    """One sampling round of sample_tokens as a captured hipGraph (torch.cuda.CUDAGraph is the stream /
+    graph plumbing; every node is a kernel of libt2h_hip.so).  A round is the same launch sequence with
+    the same arguments every time: t2h_schedule_advance moves the round's rows / generator offsets from
+    the run's padded tables into fixed staging buffers, the 24 layers and the sampling tail work on
+    persistent buffers, the seed is read from device memory.  Captured once per (batch, padded rows per
+    round, temperature), replayed for every round of every run."""
+
+    def __init__(self, net, B, T, steps, maxr, n_books, n_class, temp, mask_id, dev):
+        i64 = lambda *s: torch.empty(s, dtype=torch.int64, device=dev)
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        self.net, self.maxr, self.temp, self.mask_id = net, maxr, float(temp), mask_id
+        self.x_t, self.out, self.segm, self.tex = i64(B, T), i64(n_books, B * T), i64(B, T), i64(B, T)
+        self.rows_tbl, self.offs_tbl = i32(steps, maxr), i64(steps, maxr)
+        self.cur_rows, self.cur_offs = i32(maxr), i64(maxr)
+        self.round_ctr, self.seed = i32(1), i64(1)
+        self.logits_ws = torch.empty((maxr, n_class), dtype=torch.float32, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph = None
+
+    def body(self):
+        net, P, nm = self.net, self.net.P, self.net.name
+        ops.schedule_advance(self.rows_tbl, self.offs_tbl, None, self.round_ctr, self.cur_rows, self.cur_offs, None,
+                             self.maxr)
+        net.hidden(self.x_t, self.segm, self.tex, defer_tail=True)
+        hidden, compact = net.finish_tail(self.cur_rows, self.maxr)
+        ops.sample_heads(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'], {}, self.cur_rows, self.maxr,
+                         self.tex.view(-1), self.temp, self.x_t, self.out,
+                         row_noise=('philox', self.seed, self.cur_offs), hidden_compact=compact, logits_ws=self.logits_ws)
+
+    def run(self, sched, segm_tok, tex_tok):
+        """All rounds of one run on this graph's stream; returns `out` (valid once the caller's stream
+        has waited, which this does)."""
+        order, offs = sched.host
+        R, maxr = sched.n_rounds, self.maxr
+        rows_tbl = np.empty((R, maxr), dtype=np.int32)
+        offs_tbl = np.empty((R, maxr), dtype=np.int64)
+        for r in range(R):
+            lo, hi = int(sched.start[r]), int(sched.start[r + 1])
+            k = hi - lo
+            rows_tbl[r, :k], offs_tbl[r, :k] = order[lo:hi], offs[lo:hi]
+            rows_tbl[r, k:], offs_tbl[r, k:] = order[hi - 1], offs[hi - 1]   # padding = the round's last row again
+        caller = torch.cuda.current_stream()
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            ops.split_overflow(reset=True)  # (this stream's flag; allocated here, before any capture)
+            self.rows_tbl[:R].copy_(torch.from_numpy(rows_tbl), non_blocking=False)
+            self.offs_tbl[:R].copy_(torch.from_numpy(offs_tbl), non_blocking=False)
+            self.segm.copy_(segm_tok)
+            self.tex.copy_(tex_tok)
+            self.x_t.fill_(self.mask_id)
+            self.out.fill_(-1)
+            self.round_ctr.zero_()
+            self.seed.fill_(int(sched.seed))
+            first = 0
+            if self.graph is None:
+                self.body()  # round 0 eagerly: sizes every cached buffer before the capture
+                first = 1
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):
+                    self.body()
+                self.graph = g
+            for _ in range(first, R):
+                self.graph.replay()
+            check_split_overflow('index sampler')
+        caller.wait_stream(self.stream)
+        return self.out
 
 
 def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise=None,
@@ -457,10 +530,20 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     tex_flat = tex_tok.reshape(-1).contiguous()
     sched = build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact)
     net.last_stats = schedule.stats(sched.round_steps, sample_steps)
+    defer = bool(split and getattr(net, 'split_mha', False) and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
+    # T2H_GRAPH=1: every round is one replay of a captured launch sequence (RoundGraph) instead of ~180
+    # launches from this thread.  The GPU work is the same; what changes is the host side.
+    if (os.environ.get('T2H_GRAPH', '0') == '1' and defer and sched.noise_kind == 'philox' and step_hook is None
+            and round_hook is None and 0 < sched.max_rows <= net.TRIM_MAX_ROWS and ops.gemm_profile_active() is False):
+        maxr = min(net.TRIM_MAX_ROWS, -(-sched.max_rows // 16) * 16)
+        net._buffers(n, net.desc['C'], dev)  # (a change of batch size drops the graphs of the old buffers)
+        key = (B, T, sample_steps, maxr, float(temp), int(mask_id), n_books)
+        if key not in net._graphs:
+            net._graphs[key] = RoundGraph(net, B, T, sample_steps, maxr, n_books, n_class, temp, mask_id, dev)
+        return net._graphs[key].run(sched, segm_tok, tex_tok).clone()
     x_t = torch.full((B, T), mask_id, dtype=torch.int64, device=dev)
     out = torch.full((n_books, n), -1, dtype=torch.int64, device=dev)
     logits_ws = torch.empty((max(sched.max_rows, 1), n_class), dtype=torch.float32, device=dev)
-    defer = bool(split and getattr(net, 'split_mha', False) and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
     for r in range(sched.n_rounds):
         lo, hi = int(sched.start[r]), int(sched.start[r + 1])
         hidden = net.hidden(x_t, segm_tok, tex_tok, defer_tail=True) if defer else net.hidden(x_t, segm_tok, tex_tok)

@@ -63,6 +63,10 @@ def gemm_profile_start(every=1):
     _prof = dict(every=max(1, int(every)), count=0, recs=[])
 
 
+def gemm_profile_active():
+    return _prof is not None
+
+
 def gemm_profile_stop():
     """-> {kernel label: dict(kernel, n, ms, flops)} (synchronises)."""
     global _prof
@@ -502,6 +506,12 @@ def unmask_schedule(seed, offset, tex, steps, n_heads, n_class):
     return step_of_row, head_mask, rand_inc, expo_inc
 
 
+def schedule_advance(rows_tbl, aux64_tbl, aux32_tbl, round_ctr, cur_rows, cur_aux64, cur_aux32, maxr):
+    """Round cursor (t2h_schedule_advance): cur_* <- round *round_ctr of the padded tables; *round_ctr += 1."""
+    check(_lib.load().t2h_schedule_advance(_p(rows_tbl), _p(aux64_tbl), _p(aux32_tbl), _p(round_ctr), _p(cur_rows),
+                                           _p(cur_aux64), _p(cur_aux32), int(maxr), _stream()), 't2h_schedule_advance')
+
+
 def gather_rows(src, rows, n_rows, out=None):
     """out[i] = src[rows[i]] (rows int32 on the device, first n_rows used); src 2-D+ contiguous, any dtype
     whose row is a multiple of 16 bytes."""
@@ -547,7 +557,12 @@ def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex,
         if row_noise[0] == 'philox':
             _, seed, offs = row_noise
             assert offs.dtype == torch.int64 and offs.is_cuda and offs.numel() >= int(n_rows)
-            a.philox_seed, a.row_philox_offset = int(seed), offs.data_ptr()
+            a.row_philox_offset = offs.data_ptr()
+            if torch.is_tensor(seed):  # the seed lives in device memory (graph replay)
+                assert seed.dtype == torch.int64 and seed.is_cuda and seed.numel() == 1
+                a.philox_seed_dev = seed.data_ptr()
+            else:
+                a.philox_seed = int(seed)
             a.philox_grid_threads = torch_draw_geometry(n * n_class, hidden.device)[0]
         else:
             _, erows, slots = row_noise
