@@ -191,7 +191,14 @@ int t2h_groupnorm_finalize_f32(const double* part, int32_t chunks, const float* 
                                float* scale, float* shift, int32_t n_img, int32_t HW, int32_t C,
                                int32_t groups, float eps, void* stream);
 
-/* in-place row softmax of [rows, n] (AttnBlock, vqgan_arch.py:647) */
+/* AttnBlock's attention (vqgan_arch.py:645-656: bmm -> * C^-0.5 -> softmax -> bmm) flash-style: the
+ * N x N score matrix is never written.  qkv rows [n_img * N, >= 3C] (row stride ld) hold q | k | v of one
+ * head of width C (256 or 512); out rows [n_img * N, C] (stride ldo).  Exact fp32 matrix instructions;
+ * N % 32 == 0.  Used by the decoders' AttnBlocks (N = 512 / 2048, 2048 / 8192 at 1024x512). */
+int t2h_spatial_attention_f32(const float* qkv, int32_t ld, float* out, int32_t ldo, int32_t n_img, int32_t N,
+                              int32_t C, float scale, void* stream);
+/* in-place row softmax of [rows, n] (AttnBlock, vqgan_arch.py:647; the encoders' AttnBlocks keep the
+ * materialised form: t2h_gemm_f32 batched -> this -> t2h_gemm_f32 batched) */
 int t2h_softmax_rows_f32(float* x, int32_t rows, int32_t n, int32_t ld, void* stream);
 
 /* ------------------------------------------------------ sampler ------------

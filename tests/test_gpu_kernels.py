@@ -500,3 +500,32 @@ def test_error_reporting():
     a, w = torch.zeros(64, 48, device=DEV), torch.zeros(32, 48, device=DEV)
     with pytest.raises(T2HError, match='multiple of 32'):
         ops.gemm(a, w)
+
+
+# ------------------------------------------------------------------ decoder AttnBlock, flash-style
+
+
+@pytest.mark.parametrize('n_img,N,C', [(2, 512, 512), (3, 2048, 512), (1, 8192, 512), (2, 512, 256), (1, 96, 256)])
+def test_spatial_attention_matches_fp64_and_the_materialised_form(n_img, N, C):
+    """t2h_spatial_attention_f32 (no N x N tensor) vs an fp64 reference of vqgan_arch.py:645-656, next to
+    the materialised bmm -> softmax -> bmm form the encoders keep; a spiked key forces the online-softmax
+    rescale."""
+    qkv = rnd(n_img * N, 3 * C, seed=60 + N % 7) * 0.7
+    qkv[5, C:2 * C] *= 5.0                                  # one key far above the rest
+    qkv[N // 2 + 3, C:2 * C] *= -4.0
+    q, k, v = [t.reshape(n_img, N, C).double() for t in qkv.split(C, dim=1)]
+    ref = (torch.softmax(q @ k.transpose(1, 2) * float(int(C)**(-0.5)), -1) @ v).reshape(n_img * N, C)
+    d = qkv.to(DEV)
+    got = ops.spatial_attention(d, n_img, N, C).cpu().double()
+    q3 = d.view(n_img, N, 3 * C)
+    s = torch.empty((n_img, N, N), device=DEV)
+    ops.bgemm(q3[:, :, :C], q3[:, :, C:2 * C], s, alpha=float(int(C)**(-0.5)))
+    ops.softmax_rows_(s)
+    mat = torch.empty((n_img, N, C), device=DEV)
+    ops.bgemm(s, q3[:, :, 2 * C:], mat, b_trans=True)
+    e_new, e_old = (got - ref).abs().max().item(), (mat.cpu().double().view(-1, C) - ref).abs().max().item()
+    assert e_new < 2e-5 + 3 * e_old, (e_new, e_old)
+    # strided output (a column block of a wider buffer)
+    wide = torch.zeros(n_img * N, C + 64, device=DEV)
+    ops.spatial_attention(d, n_img, N, C, out=wide[:, :C])
+    assert torch.equal(wide[:, :C].cpu().double(), got) and (wide[:, C:] == 0).all()

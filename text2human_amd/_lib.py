@@ -83,6 +83,7 @@ SIGNATURES = {
     't2h_groupnorm_tables_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                                 c_i32, c_i32, c_f32, c_vp, c_vp]),
     't2h_groupnorm_finalize_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    't2h_spatial_attention_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     't2h_softmax_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_embed_sum4_f32': (ctypes.c_int, [c_vp] * 8 + [c_i32, c_i32, c_i32, c_vp]),
     't2h_mha_noncausal_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -26,6 +26,9 @@ class VQGANStack:
     def __init__(self, P, name, desc):
         self.P, self.name, self.desc = P, name, desc
         self.use_split = True  # False: exact-fp32 convolutions even if split-row weights were packed (A/B, bench parity)
+        # the decoders' AttnBlocks (N = 512 .. 8192 positions) run flash-style; the encoders' (tokenizer: an argmin
+        # decision pinned to golden tokens) keep the materialised bmm -> softmax -> bmm form
+        self.flash_attn = False
 
     def _ws(self, key, hw, mode='same'):
         """Split-row weights of `key` if the stack was packed with them (weights.add_split_conv_weights)
@@ -80,6 +83,8 @@ class VQGANStack:
         """AttnBlock.forward (vqgan_arch.py:636-661)."""
         c = x.shape[1]
         qkv = self._conv1x1(x, f'{pfx}.qkv', n, pro=self._gn(x, f'{pfx}.norm', n_img, n))
+        if self.flash_attn and ops.spatial_attention_ok(n, c):
+            return self._conv1x1(ops.spatial_attention(qkv, n_img, n, c), f'{pfx}.proj', n, residual=x)
         q3 = qkv.view(n_img, n, 3 * c)
         s = torch.empty((n_img, n, n), device=x.device, dtype=torch.float32)
         ops.bgemm(q3[:, :, :c], q3[:, :, c:2 * c], s, alpha=float(int(c)**(-0.5)))

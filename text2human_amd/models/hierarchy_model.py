@@ -25,6 +25,7 @@ class VQGANTextureAwareSpatialHierarchyInferenceModel():
         self.bot_encoder = engine.VQGANStack(P, 'benc', weights.pack_vqgan(P, sds['bot_encoder'], 'benc'))
         self.decoder = engine.VQGANStack(P, 'dec', weights.pack_vqgan(P, sds['decoder'], 'dec'))
         self.bot_decoder_res = engine.VQGANStack(P, 'res', weights.pack_vqgan(P, sds['bot_decoder_res'], 'res'))
+        self.decoder.flash_attn = self.bot_decoder_res.flash_attn = True
         self.cin_pad = P['tenc.conv_in.w'].shape[1] // 9
         P.put('top.books', weights.stack_codebooks(sds['top_quantize']))
         P.put('bot.books', weights.stack_codebooks(sds['bot_quantize']))

@@ -56,6 +56,7 @@ class BaseSampleModel():
             weights.add_split_conv_weights(P, 'res')
         self.decoder = engine.VQGANStack(P, 'dec', d_dec)
         self.bot_decoder_res = engine.VQGANStack(P, 'res', d_res)
+        self.decoder.flash_attn = self.bot_decoder_res.flash_attn = True
         self.segm_encoder = engine.VQGANStack(P, 'senc', d_enc)
         self.segm_cin_pad = P['senc.conv_in.w'].shape[1] // 9
         P.put('top.books', weights.stack_codebooks(sds['top_quantize']))

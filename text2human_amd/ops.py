@@ -416,6 +416,21 @@ def groupnorm_tables(x, gamma, beta, n_img, hw, groups=32, eps=1e-6):
     return scale, shift
 
 
+def spatial_attention(qkv, n_img, n, c, out=None):
+    """AttnBlock attention without the N x N tensor: qkv rows [n_img * n, 3c] (q | k | v) -> rows [n_img * n, c]."""
+    _chk_f32(qkv, out)
+    assert qkv.shape == (n_img * n, 3 * c) and c in (256, 512) and n % 32 == 0
+    if out is None:
+        out = torch.empty((n_img * n, c), device=qkv.device, dtype=torch.float32)
+    check(_lib.load().t2h_spatial_attention_f32(_p(qkv), _rows(qkv), _p(out), _rows(out), n_img, n, c, float(int(c)**(-0.5)),
+                                                _stream()), 't2h_spatial_attention_f32')
+    return out
+
+
+def spatial_attention_ok(n, c):
+    return c in (256, 512) and n % 32 == 0
+
+
 def softmax_rows_(x):
     _chk_f32(x)
     x2 = x.view(-1, x.shape[-1])
