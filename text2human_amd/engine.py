@@ -83,7 +83,11 @@ class VQGANStack:
         """AttnBlock.forward (vqgan_arch.py:636-661)."""
         c = x.shape[1]
         qkv = self._conv1x1(x, f'{pfx}.qkv', n, pro=self._gn(x, f'{pfx}.norm', n_img, n))
-        if self.flash_attn and ops.spatial_attention_ok(n, c):
+        # flash-style (no N x N tensor) once the launch fills the chip (32 queries per workgroup, >= one
+        # workgroup per CU): N = 2048 at B = 8, N = 8192 at 1024x512.  Below that (the top decoder's N = 512:
+        # 8 MB of scores for 8 images) the materialised form is 2x faster and its tensor is small.
+        # profiles/r03_spatial_attention_bench.log
+        if self.flash_attn and ops.spatial_attention_ok(n, c) and n_img * (n // 32) >= 256:
             return self._conv1x1(ops.spatial_attention(qkv, n_img, n, c), f'{pfx}.proj', n, residual=x)
         q3 = qkv.view(n_img, n, 3 * c)
         s = torch.empty((n_img, n, n), device=x.device, dtype=torch.float32)
