@@ -156,58 +156,68 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   }
 }
 
-// Grid n_img, block = C threads (<= 1024): thread c reduces its channel over the
-// chunks, groups are combined through LDS, then scale/shift tables are emitted.
-__global__ void gn_finalize_kernel(const double* __restrict__ part, int chunks, int HW, int C,
-                                   int groups, float eps, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
-  __shared__ double cs[1024], css[1024];
-  __shared__ float g_mean[64], g_rstd[64];
-  const int c = threadIdx.x, img = blockIdx.x;
+// Grid (groups, n_img), 256 threads: a workgroup owns ONE GroupNorm group of one image -- its cpg = C /
+// groups channels (4 .. 32) -- and spreads the `chunks` per-tile partials of those channels over
+// 256 / cpg slices of consecutive chunks (a conv epilogue leaves up to 4096 of them per image at
+// 1024x512; one workgroup per image walking them alone took 60-100 us per GroupNorm there).  Every slice
+// sums in chunk order, the slices are combined in slice order: a fixed summation tree, in fp64.
+constexpr int GNF_THREADS = 256;
+__global__ __launch_bounds__(GNF_THREADS) void gn_finalize_kernel(const double* __restrict__ part, int chunks, int HW,
+                                                                 int C, int groups, float eps,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double cs[GNF_THREADS], css[GNF_THREADS];
+  __shared__ float g_stat[2];
+  const int g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / groups;              // host: cpg divides 256
+  const int slices = GNF_THREADS / cpg;
+  const int ch = tid % cpg, sl = tid / cpg;
+  const int per = (chunks + slices - 1) / slices;
+  const int k0 = sl * per, k1 = min(chunks, k0 + per);
+  const double* p = part + ((int64_t)img * chunks * 2) * C + g * cpg + ch;
   double s = 0, ss = 0;
-  int k = 0;
-  for (; k + 8 <= chunks; k += 8) {  // 16 independent loads in flight (up to 1024 chunks when the partials
-    double a[8], b[8];               // come from a conv epilogue); the additions stay in chunk order
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {  // 8 independent loads in flight; the additions stay in chunk order
+    double a[4], b[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const double* p = part + (((int64_t)img * chunks + k + j) * 2) * C;
-      a[j] = p[c];
-      b[j] = p[C + c];
+    for (int j = 0; j < 4; ++j) {
+      a[j] = p[(int64_t)(k + j) * 2 * C];
+      b[j] = p[(int64_t)(k + j) * 2 * C + C];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
       s += a[j];
       ss += b[j];
     }
   }
-  for (; k < chunks; ++k) {
-    const double* p = part + (((int64_t)img * chunks + k) * 2) * C;
-    s += p[c];
-    ss += p[C + c];
+  for (; k < k1; ++k) {
+    s += p[(int64_t)k * 2 * C];
+    ss += p[(int64_t)k * 2 * C + C];
   }
-  cs[c] = s;
-  css[c] = ss;
+  cs[tid] = s;
+  css[tid] = ss;
   __syncthreads();
-  const int cpg = C / groups;
-  if (c < groups) {
+  if (tid == 0) {
     double a = 0, b = 0;
-    for (int i = 0; i < cpg; ++i) {
-      a += cs[c * cpg + i];
-      b += css[c * cpg + i];
+    for (int i = 0; i < GNF_THREADS; ++i) {  // slice-major, channel-minor: a fixed order
+      a += cs[i];
+      b += css[i];
     }
     const double n = (double)HW * cpg;
     const double mean = a / n;
     double var = b / n - mean * mean;
     if (var < 0) var = 0;
-    g_mean[c] = (float)mean;
-    g_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    g_stat[0] = (float)mean;
+    g_stat[1] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
-  const int g = c / cpg;
-  const float sc = g_rstd[g] * gamma[c];
-  scale[(int64_t)img * C + c] = sc;
-  shift[(int64_t)img * C + c] = fmaf(-g_mean[g], sc, beta[c]);
+  if (tid < cpg) {
+    const int c = g * cpg + tid;
+    const float sc = g_stat[1] * gamma[c];
+    scale[(int64_t)img * C + c] = sc;
+    shift[(int64_t)img * C + c] = fmaf(-g_stat[0], sc, beta[c]);
+  }
 }
 
 // In-place softmax of each row; one wave per row, the row (n <= 64*MAXV) stays
@@ -300,13 +310,14 @@ extern "C" int t2h_groupnorm_tables_f32(const float* x, int32_t ldx, const float
   T2H_REQUIRE(n_img > 0 && HW > 0, "t2h_groupnorm_tables_f32: empty problem");
   T2H_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && C / 4 <= 256,
               "t2h_groupnorm_tables_f32: C=%d unsupported", C);
-  T2H_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "t2h_groupnorm_tables_f32: groups=%d", groups);
+  T2H_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0 && GNF_THREADS % (C / groups) == 0,
+              "t2h_groupnorm_tables_f32: groups=%d (C / groups must divide 256)", groups);
   T2H_REQUIRE(ldx % 4 == 0 && t2h_aligned16(x), "t2h_groupnorm_tables_f32: alignment");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int chunks = gn_chunks(HW);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n_img), dim3(256), 0, s, x, ldx, HW, C, chunks,
                      static_cast<double*>(workspace));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img), dim3(C), 0, s,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_img), dim3(GNF_THREADS), 0, s,
                      static_cast<const double*>(workspace), chunks, HW, C, groups, eps, gamma, beta,
                      scale, shift);
   T2H_CHECK_LAUNCH("t2h_groupnorm_tables_f32");
@@ -317,10 +328,11 @@ extern "C" int t2h_groupnorm_finalize_f32(const double* part, int32_t chunks, co
                                           float* scale, float* shift, int32_t n_img, int32_t HW, int32_t C,
                                           int32_t groups, float eps, void* stream) {
   T2H_REQUIRE(part && gamma && beta && scale && shift, "t2h_groupnorm_finalize_f32: NULL pointer");
-  T2H_REQUIRE(n_img > 0 && HW > 0 && chunks > 0 && C > 0 && C <= 1024 && groups > 0 && groups <= 64 && C % groups == 0,
-              "t2h_groupnorm_finalize_f32: bad shape (C <= 1024, groups <= 64)");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img), dim3(C), 0, static_cast<hipStream_t>(stream), part, chunks, HW,
-                     C, groups, eps, gamma, beta, scale, shift);
+  T2H_REQUIRE(n_img > 0 && HW > 0 && chunks > 0 && C > 0 && C <= 1024 && groups > 0 && groups <= 64 && C % groups == 0 &&
+                  GNF_THREADS % (C / groups) == 0,
+              "t2h_groupnorm_finalize_f32: bad shape (C <= 1024, groups <= 64, C / groups divides 256)");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_img), dim3(GNF_THREADS), 0, static_cast<hipStream_t>(stream),
+                     part, chunks, HW, C, groups, eps, gamma, beta, scale, shift);
   T2H_CHECK_LAUNCH("t2h_groupnorm_finalize_f32");
   return T2H_OK;
 }
