@@ -103,6 +103,14 @@ int t2h_gemm_force_config(int cfg);
  * C, residual, bias stay fp32.  Replaces t2h_gemm_f32 at vqgan_arch.py:597-617,529-534,636-661,
  * 1000-1033,1136-1151 (opt-out: T2H_SPLIT_CONV=0). */
 int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
+/* 3x3 'same' convolution with 1..4 output channels (the decoders' conv_out, vqgan_arch.py:997,1026-1033) on
+ * the vector ALU, exact fp32: out[pixel][co] = bias[co] + sum over taps, channels of
+ * act(x * scale[img] + shift[img]) * w[co][tap][c] (scale NULL = no prologue; act 1 = swish), zero padding of
+ * the ACTIVATED tensor.  x rows [n_img*H*W, >= Cin] (stride ldx), w packed [Cout][9][Cin] like t2h_gemm_f32's
+ * conv mode, out rows (stride ldo >= Cout).  Cin % 32 == 0. */
+int t2h_conv3x3_small_f32(const float* x, int32_t ldx, const float* w, const float* bias, const float* scale,
+                          const float* shift, int32_t tbl_ld, int32_t act, float* out, int32_t ldo, int32_t n_img,
+                          int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 int t2h_conv_split_force_tile(int rows); /* tuning / tests (thread-local): 128 or 256 output pixels per tile, 0 auto; returns the old value */
 /* out_split[row] = split( act( x[row] * scale[img] + shift[img] ) ): GroupNorm apply (tables of
  * t2h_groupnorm_tables_f32; NULL = plain split) + swish (act 1) of fp32 NHWC rows in one pass

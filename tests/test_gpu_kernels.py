@@ -529,3 +529,26 @@ def test_spatial_attention_matches_fp64_and_the_materialised_form(n_img, N, C):
     wide = torch.zeros(n_img * N, C + 64, device=DEV)
     ops.spatial_attention(d, n_img, N, C, out=wide[:, :C])
     assert torch.equal(wide[:, :C].cpu().double(), got) and (wide[:, C:] == 0).all()
+
+
+@pytest.mark.parametrize('n_img,H,W,cin,cout,pro', [(2, 32, 64, 128, 3, True), (1, 13, 37, 64, 3, True), (3, 8, 32, 32, 4, False),
+                                                   (1, 24, 40, 128, 1, True)])
+def test_conv3x3_small_matches_fp64(n_img, H, W, cin, cout, pro):
+    """t2h_conv3x3_small_f32 (conv_out: a few output channels, GroupNorm-apply + swish prologue, zero padding
+    of the ACTIVATED tensor) vs an fp64 reference and next to the matrix-core kernel it replaces."""
+    x = rnd(n_img, cin, H, W, seed=70 + H) * 1.5
+    w = rnd(cout, cin, 3, 3, seed=71, scale=0.08)
+    b = rnd(cout, seed=72)
+    sc, sh = rnd(n_img, cin, seed=73) * 0.3 + 1.0, rnd(n_img, cin, seed=74) * 0.5
+    a = x.double()
+    if pro:
+        a = a * sc.double()[:, :, None, None] + sh.double()[:, :, None, None]
+        a = a * torch.sigmoid(a)
+    ref = F.conv2d(a, w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(DEV)
+    wp = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)      # [Cout][tap][cin]
+    p = (sc.to(DEV), sh.to(DEV), ops.PRO_SWISH) if pro else None
+    got = ops.conv3x3_small(rows, wp, n_img, H, W, cin, bias=b.to(DEV), pro=p)
+    old = ops.conv3x3(rows, wp, n_img, H, W, cin, bias=b.to(DEV), pro=p)
+    e_new, e_old = (got.cpu().double() - ref).abs().max().item(), (old.cpu().double() - ref).abs().max().item()
+    assert e_new < 2e-5 + 3 * e_old, (e_new, e_old)

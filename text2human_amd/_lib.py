@@ -65,6 +65,8 @@ class SampleHeadsArgs(ctypes.Structure):
 SIGNATURES = {
     't2h_gemm_split_f32': (ctypes.c_int, [ctypes.POINTER(GemmSplitArgs), c_vp]),
     't2h_gemm_split_force_config': (ctypes.c_int, [ctypes.c_int]),
+    't2h_conv3x3_small_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                             c_i32, c_i32, c_vp]),
     't2h_conv_split_force_tile': (ctypes.c_int, [ctypes.c_int]),
     't2h_split_overflow': (ctypes.c_int, [c_i32, c_vp]),
     't2h_split_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i32, c_vp]),

@@ -55,6 +55,9 @@ class VQGANStack:
                                     act=PRO_SWISH if pro is not None else PRO_NONE)
             return ops.conv_split(xs, ws, n_img, h, w, cin, cout, bias=P[f'{conv}.b'], residual=residual, mode=mode,
                                   gn_stats=cout <= 1024)
+        if residual is None and ops.conv3x3_small_ok(cin, cout, mode):  # conv_out: 3 output channels
+            return ops.conv3x3_small(x, P[f'{conv}.w'], n_img, h, w, cin, bias=P[f'{conv}.b'],
+                                     pro=(pro[0], pro[1], PRO_SWISH) if pro is not None else None)
         return ops.conv3x3(x, P[f'{conv}.w'], n_img, h, w, cin, bias=P[f'{conv}.b'], mode=mode, residual=residual,
                            pro=(pro[0], pro[1], PRO_SWISH) if pro is not None else None)
 

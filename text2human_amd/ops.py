@@ -255,6 +255,26 @@ def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=
     return out
 
 
+def conv3x3_small(x, w, n_img, h, wd, cin, bias=None, pro=None, out=None):
+    """3x3 'same' convolution with <= 4 output channels (conv_out) on the vector ALU, exact fp32;
+    pro = (scale[n_img, C], shift[n_img, C], pro_act) as for conv3x3."""
+    _chk_f32(x, w, bias, out)
+    cout = w.shape[0]
+    assert w.shape[1] == 9 * cin and x.shape[0] == n_img * h * wd and w.is_contiguous()
+    if out is None:
+        out = torch.empty((n_img * h * wd, cout), device=x.device, dtype=torch.float32)
+    sc, sh, pact = pro if pro is not None else (None, None, PRO_NONE)
+    _chk_f32(sc, sh)
+    check(_lib.load().t2h_conv3x3_small_f32(_p(x), _rows(x), _p(w), _p(bias), _p(sc), _p(sh),
+                                            sc.shape[1] if sc is not None else 0, int(pact), _p(out), _rows(out), n_img, h,
+                                            wd, cin, cout, _stream()), 't2h_conv3x3_small_f32')
+    return out
+
+
+def conv3x3_small_ok(cin, cout, mode):
+    return mode == 'same' and cout <= 4 and cin % 32 == 0
+
+
 def layernorm(x, gamma, beta, out=None, eps=1e-5):
     _chk_f32(x, gamma, beta, out)
     assert x.is_contiguous()
