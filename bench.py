@@ -329,10 +329,17 @@ def gemm_roofline(prof, config):
         'frac_useful': eq / peak,
         'fp32_equivalent_tflops': eq, 'frac_of_fp32_mfma_peak': eq / FP32_MFMA_PEAK_TFLOPS,
         'launches_sampled': dom['n'], 'avg_launch_us': 1000.0 * dom['ms'] / dom['n'],
-        'avg_launch_us_basis': 'HIP events recorded on the launch stream either side of every 37th launch: the '
-                               'interval runs from the END of the previous kernel to the end of this one, i.e. kernel '
-                               'time + the dependent-launch boundary (~2-3 us); rocprofv3 kernel-trace durations '
-                               '(avg_launch_us_rocprof) exclude the boundary',
+        'avg_launch_us_basis': ('HIP events that receive the START and END of the kernel itself (hipExtLaunchKernelGGL, '
+                                'every 37th launch of the timed region): the duration rocprofv3\'s kernel trace reports '
+                                '(avg_launch_us_rocprof, from the committed profile of the same command).  '
+                                'avg_stream_interval_us: events recorded on the stream around '
+                                'OTHER sampled launches, i.e. from the end of the previous kernel: kernel + dependent-launch boundary'
+                                if dom.get('kernel_timed') else
+                                'HIP events recorded on the launch stream around every 37th launch: kernel time + the '
+                                'dependent-launch boundary'),
+        'avg_stream_interval_us': (1000.0 * dom['ms_stream'] / dom['n_stream'] if dom.get('n_stream') else None),
+        'frac_incl_launch_boundary': (mult * dom['flops_stream'] / (dom['ms_stream'] * 1e-3) / 1e12 / peak
+                                      if dom.get('n_stream') else None),
         'flop_per_launch': mult * dom['flops'] / dom['n'],
         'all_gemm_kernels': {k: {'TFLOP/s': v['flops'] / (v['ms'] * 1e-3) / 1e12, 'n': v['n'],
                                  'avg_us': 1000.0 * v['ms'] / v['n']} for k, v in prof.items()},
@@ -340,6 +347,7 @@ def gemm_roofline(prof, config):
     r.update(profile_side_data(dom['kernel'], config))
     if r.get('avg_launch_us_rocprof'):
         r['frac_rocprof_kernel_time'] = r['frac'] * r['avg_launch_us'] / r['avg_launch_us_rocprof']
+        r['rocprof_vs_live_kernel_time'] = r['avg_launch_us_rocprof'] / r['avg_launch_us']
     return r
 
 

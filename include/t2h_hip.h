@@ -162,6 +162,10 @@ int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
  * last reset, 0 if not, < 0 on error; reset != 0 clears it.  The host side clears it at the start of a
  * sampling run / decode and checks it at the end. */
 int t2h_split_overflow(int32_t reset, void* stream);
+/* measurement hook (bench.py): the NEXT t2h_gemm_split_f32 launch of the calling thread records its own
+ * start / end into the two hipEvent_t (hipExtLaunchKernelGGL: the kernel's timestamps, what rocprofv3's
+ * kernel trace reports), then the hook disarms.  NULL, NULL disarms. */
+int t2h_gemm_split_time_next_launch(void* start_event, void* stop_event);
 int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..3, 5, 6, 8 / 10 (ping-pong LDS-DMA, 256x128 / 128x192), 9 (few-rows kernel), -1 auto;
                                               thread-local: it affects launches of the calling thread only */
 /* fp32 [rows, C] (row stride ldx) -> split rows */

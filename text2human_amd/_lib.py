@@ -64,6 +64,7 @@ class SampleHeadsArgs(ctypes.Structure):
 # name -> (restype, argtypes); must list EVERY symbol declared in include/t2h_hip.h
 SIGNATURES = {
     't2h_gemm_split_f32': (ctypes.c_int, [ctypes.POINTER(GemmSplitArgs), c_vp]),
+    't2h_gemm_split_time_next_launch': (ctypes.c_int, [c_vp, c_vp]),
     't2h_gemm_split_force_config': (ctypes.c_int, [ctypes.c_int]),
     't2h_conv3x3_small_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32,
                                              c_i32, c_i32, c_vp]),

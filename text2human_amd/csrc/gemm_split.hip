@@ -24,6 +24,7 @@
 // free.  Main loop = the same two-register-set, counted-vmcnt software pipeline as
 // the fp32 kernel (gemm.hip): staged pieces are written to LDS and re-issued in the
 // shadow of the MFMAs.
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -672,6 +673,22 @@ __global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t
   t2h_store_split4(out, row, C, c0, *reinterpret_cast<const f32x4*>(x + row * ldx + c0), ovf);
 }
 
+// t2h_gemm_split_time_next_launch: events that receive the START and the END of the next kernel this
+// thread launches (hipExtLaunchKernelGGL: timestamps of the kernel itself, what rocprofv3's kernel
+// trace reports) -- events recorded around a launch on the stream measure from the end of the
+// PREVIOUS kernel and so include the dependent-launch boundary
+thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+
+template <typename K, typename... Args>
+void launch_maybe_timed(K kernel, dim3 grid, dim3 block, hipStream_t s, Args... args) {
+  if (g_time_start && g_time_stop) {
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, s, g_time_start, g_time_stop, 0, args...);
+    g_time_start = g_time_stop = nullptr;
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+  }
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1, int PP = 0>
 int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE(a.K % (32 * KS) == 0, "t2h_gemm_split_f32: this tile config needs K %% %d == 0", 32 * KS);
@@ -683,8 +700,8 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
   int* ovf = t2h_split_overflow_flag_ptr(s);
   T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP>), grid,
-                     dim3(64 * WARPS_M * WARPS_N * KS), 0, s, a, ovf);
+  launch_maybe_timed(gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP>, grid, dim3(64 * WARPS_M * WARPS_N * KS), s, a,
+                     ovf);
   T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
   return T2H_OK;
 }
@@ -698,6 +715,12 @@ extern "C" int t2h_debug_set_gemm1_timing_buffer(void* dev_ptr) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g1_timing), &dev_ptr, sizeof(void*));
 }
 #endif
+
+extern "C" int t2h_gemm_split_time_next_launch(void* start_event, void* stop_event) {
+  g_time_start = static_cast<hipEvent_t>(start_event);
+  g_time_stop = static_cast<hipEvent_t>(stop_event);
+  return T2H_OK;
+}
 
 extern "C" int t2h_gemm_split_force_config(int cfg) {
   const int old = g_force_split_cfg;
@@ -756,7 +779,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     T2H_REQUIRE(skinny_ok, "t2h_gemm_split_f32: the few-rows kernel needs N %% 16 == 0 and no Vt routing");
     int* ovf = t2h_split_overflow_flag_ptr(s);
     T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
-    hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), 0, s, a, ovf);
+    launch_maybe_timed(gemm_split_skinny_kernel, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), s, a, ovf);
     T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
     return T2H_OK;
   }

@@ -75,8 +75,15 @@ def gemm_profile_stop():
         return {}
     torch.cuda.synchronize()
     out = {}
-    for label, flops, e0, e1 in p['recs']:
-        r = out.setdefault(label, dict(kernel=label, n=0, ms=0.0, flops=0.0))
+    for label, flops, e0, e1, *kind in p['recs']:
+        r = out.setdefault(label, dict(kernel=label, n=0, ms=0.0, flops=0.0, n_stream=0, ms_stream=0.0, flops_stream=0.0,
+                                       kernel_timed=False))
+        if kind and kind[0] == 'stream':  # interval on the stream: kernel + launch boundary
+            r['n_stream'] += 1
+            r['ms_stream'] += e0.elapsed_time(e1)
+            r['flops_stream'] += flops
+            continue
+        r['kernel_timed'] = r['kernel_timed'] or bool(kind)
         r['n'] += 1
         r['ms'] += e0.elapsed_time(e1)
         r['flops'] += flops
@@ -353,13 +360,27 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     lib = _lib.load()
     if _prof is not None:
         _prof['count'] += 1
-        if _prof['count'] % _prof['every'] == 0:
-            # algorithmic (fp32-equivalent) FLOPs; the kernel issues 3 fp16 products per multiply
+        phase = _prof['count'] % _prof['every']
+        # algorithmic (fp32-equivalent) FLOPs; the kernel issues 3 fp16 products per multiply.  Two kinds of
+        # samples, on DIFFERENT launches (timing a kernel through hipExtLaunchKernelGGL adds packets around it):
+        if phase == 0:
+            # (k0, k1) receive the kernel's OWN start / end (t2h_gemm_split_time_next_launch): kernel time
+            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k0.record()  # (creates the hipEvent_t handles the hook hands to the launch)
+            k1.record()
+            check(lib.t2h_gemm_split_time_next_launch(ctypes.c_void_p(k0.cuda_event), ctypes.c_void_p(k1.cuda_event)),
+                  't2h_gemm_split_time_next_launch')
+            check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
+            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, k0, k1, 'kernel'))
+            return out if out is not None else out_split
+        if phase == _prof['every'] // 2:
+            # (e0, e1) are recorded on the stream around the launch and so run from the end of the previous
+            # kernel: kernel + dependent-launch boundary
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
             e1.record()
-            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, e0, e1))
+            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, e0, e1, 'stream'))
             return out if out is not None else out_split
     check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
     return out if out is not None else out_split
