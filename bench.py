@@ -551,13 +551,15 @@ def main(argv=None):
 
     # ---- the other BASELINE.json configurations, inside the same (driver-run) command
     other = {}
-    if not stub and args.config == 'parsing' and not args.no_other_configs and not args.batch:
+    if args.config == 'parsing' and not args.no_other_configs and (stub or not args.batch):
         # configs[3]'s per-GPU share (batch 256 over 8 GPUs = 32 per GPU) at every N: at N = 8 its global
         # batch IS configs[3]; the headline line above keeps configs[1]'s 8 per GPU at every N (weak scaling)
-        b32, _ = shard_of('parsing', 32)
-        other['parsing_b32'] = side_config('parsing_b32', ConfigRun('parsing', model, b32, args.sample_steps, set_seed),
-                                           args.other_steps, 1, 32, world, dworld, dev)
-        if world == 1:
+        # (--stub-model: the same leg with a small batch, so that its collectives run under gloo in the tests)
+        per32 = 2 * batch_per_gpu if stub else 32
+        b32, _ = shard_of('parsing', per32)
+        other['parsing_b32'] = side_config('parsing_b32', ConfigRun('parsing', model, b32, args.sample_steps, set_seed, stub),
+                                           args.other_steps, 1, per32, world, dworld, dev)
+        if world == 1 and not stub:
             other['hires'] = side_config('hires', ConfigRun('hires', model, batch, args.sample_steps, set_seed),
                                          args.other_steps, 1, batch_per_gpu, 1, 1, dev)
             # sample_from_pose: the same five checkpoints + the parsing generator's three modules
@@ -615,6 +617,8 @@ def main(argv=None):
         'launch_thread_cores': pinned,
     }
     if stub:
+        if other:
+            out['other_configs'] = other
         print(json.dumps(out), flush=True)
         dist and dist.destroy_process_group()
         return

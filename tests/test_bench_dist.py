@@ -45,6 +45,9 @@ def test_bench_two_ranks_gloo():
     # every rank worked on ITS shard (different data -> different checksums) with broadcast weights
     cs = out['per_rank_image_checksum']
     assert len(cs) == 2 and cs[0] != cs[1]
+    # the configs[3] leg ran on both ranks too (its barrier / max-over-ranks collectives are the headline's)
+    leg = out['other_configs']['parsing_b32']
+    assert leg['config']['global_batch'] == 2 * 2 * 3 and leg['value'] > 0 and leg['steps'] == 2
     # the shards are those of the single-process run over the same global batch
     one = _run(1, ('--batch', '6'))
     assert one['rccl_world'] == 1 and len(one['per_rank_image_checksum']) == 1

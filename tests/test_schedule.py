@@ -68,3 +68,21 @@ def test_draw_offsets_follow_the_generator():
 def test_group_rounds_rejects_rows_without_a_step():
     with pytest.raises(ValueError):
         schedule.group_rounds(np.array([1, 0, 2, 1]), 1, 4)
+
+
+def test_padded_tables_repeat_a_row_of_the_same_round():
+    B, T, steps = 3, 64, 20
+    step = _random_schedule(B, T, steps, seed=11)
+    order, start, _ = schedule.group_rounds(step, B, T, compact=True)
+    vals = (order * 7 + 3).astype(np.int64)
+    widest = int(np.diff(start).max())
+    maxr = -(-widest // 16) * 16
+    rows_tbl, val_tbl = schedule.padded_tables(order, vals, start, maxr)
+    assert rows_tbl.shape == val_tbl.shape == (len(start) - 1, maxr) and rows_tbl.dtype == np.int32
+    for r in range(len(start) - 1):
+        mine = order[start[r]:start[r + 1]]
+        assert rows_tbl[r, :len(mine)].tolist() == mine.tolist()
+        assert set(rows_tbl[r, len(mine):].tolist()) <= {int(mine[-1])}         # padding = a row of THIS round
+        assert (val_tbl[r] == rows_tbl[r].astype(np.int64) * 7 + 3).all()        # values travel with their rows
+    with pytest.raises(ValueError):
+        schedule.padded_tables(order, vals, start, widest - 1)

@@ -470,14 +470,8 @@ class RoundGraph:
         """All rounds of one run on this graph's stream; returns `out` (valid once the caller's stream
         has waited, which this does)."""
         order, offs = sched.host
-        R, maxr = sched.n_rounds, self.maxr
-        rows_tbl = np.empty((R, maxr), dtype=np.int32)
-        offs_tbl = np.empty((R, maxr), dtype=np.int64)
-        for r in range(R):
-            lo, hi = int(sched.start[r]), int(sched.start[r + 1])
-            k = hi - lo
-            rows_tbl[r, :k], offs_tbl[r, :k] = order[lo:hi], offs[lo:hi]
-            rows_tbl[r, k:], offs_tbl[r, k:] = order[hi - 1], offs[hi - 1]   # padding = the round's last row again
+        R = sched.n_rounds
+        rows_tbl, offs_tbl = schedule.padded_tables(order, offs, sched.start, self.maxr)
         caller = torch.cuda.current_stream()
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):

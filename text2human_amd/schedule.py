@@ -78,6 +78,24 @@ def group_rounds(step_of_row, B, T, compact=True):
     return order, start, round_steps
 
 
+def padded_tables(order, per_row, start, maxr):
+    """The schedule as fixed-width tables for graph replay (engine.RoundGraph, t2h_schedule_advance):
+    row r of the result = the rows of round r, padded to `maxr` entries with copies of the round's LAST
+    row (sampling a row twice writes the same token twice), and the same for the per-row values
+    (generator offsets).  -> (rows int32 [R, maxr], values int64 [R, maxr])"""
+    n_rounds = len(start) - 1
+    rows_tbl = np.empty((n_rounds, maxr), dtype=np.int32)
+    val_tbl = np.empty((n_rounds, maxr), dtype=np.int64)
+    for r in range(n_rounds):
+        lo, hi = int(start[r]), int(start[r + 1])
+        k = hi - lo
+        if not 0 < k <= maxr:
+            raise ValueError(f'round {r} has {k} rows, tables are {maxr} wide')
+        rows_tbl[r, :k], val_tbl[r, :k] = order[lo:hi], per_row[lo:hi]
+        rows_tbl[r, k:], val_tbl[r, k:] = order[hi - 1], per_row[hi - 1]
+    return rows_tbl, val_tbl
+
+
 def stats(round_steps, steps):
     """Evaluation counts for the bench line: (sample, step) pairs the reference evaluates, pairs that
     change a token (the ones whose logits are read), rounds launched."""
