@@ -589,6 +589,8 @@ def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex,
     ('philox', seed, offsets int64 [>= n_rows]) = per-listed-row generator offsets, or
     ('explicit', expo_rows f32 [*, n_class], slots int32 [>= n_rows]) = per-listed-row explicit draws."""
     _chk_f32(hidden, lnf_g, lnf_b, w_heads, *expo_by_head.values())
+    if int(n_rows) == 0:
+        return
     C = hidden.shape[1]
     n = out_idx.shape[1]
     assert hidden.shape[0] == (int(n_rows) if hidden_compact else n)
