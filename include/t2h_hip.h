@@ -117,7 +117,7 @@ int t2h_conv_split_force_tile(int rows); /* tuning / tests (thread-local): 128 o
  * (vqgan_arch.py:510-517,599-600,609-610,637,1026-1027) */
 int t2h_gn_apply_split_f32(const float* x, int32_t ldx, const float* scale, const float* shift, int32_t tbl_ld,
                            uint16_t* out_split, int64_t rows, int32_t rows_per_img, int32_t C, int32_t act,
-                           void* stream);
+                           int32_t* overflow_flag, void* stream);
 
 /* ------------------------------------------------- split-precision GEMM -----
  * Same contraction on the fp16 matrix cores at fp32-class accuracy: every fp32
@@ -150,18 +150,19 @@ typedef struct t2h_gemm_split_args {
    * P*V matrix instruction contracts them.  NULL = off. */
   uint16_t* Vt;
   int32_t vt_col0, vt_T, vt_hd;
+  int32_t* overflow_flag; /* the caller's sticky overflow word (below); required with C_split / Vt */
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
-/* Sticky device-side overflow flag of every split-row producer (this GEMM's C_split / Vt
- * epilogues, t2h_split_rows_f32, t2h_layernorm_split_f32, t2h_gn_apply_split_f32, the attention
- * outputs): raised when a value about to be written as split rows has |x| >= 65504 (fp16 planes
- * would hold inf / NaN).  There is one flag PER (device, stream): a producer raises the flag of the
- * stream it was launched on, so two models driven on two streams (or threads) neither see nor clear
- * each other's state.  Synchronises `stream`, returns 1 if that stream's flag was raised since its
- * last reset, 0 if not, < 0 on error; reset != 0 clears it.  The host side clears it at the start of a
- * sampling run / decode and checks it at the end. */
-int t2h_split_overflow(int32_t reset, void* stream);
+/* Sticky overflow flag of every split-row producer (this GEMM's C_split / Vt epilogues, t2h_split_rows_f32,
+ * t2h_layernorm_split_f32, t2h_gn_apply_split_f32, the attention outputs): ONE int32 word in device memory
+ * that the CALLER allocates (zeroed) and passes as `overflow_flag`; a producer ORs 1 into it when a value about
+ * to be written as split rows has |x| >= 65504 (the fp16 planes would hold inf / NaN).  The library never
+ * allocates, reads or synchronises on it: a caller that drives several streams / models gives each its own
+ * word.  t2h_split_overflow_async enqueues on `stream` a copy of *flag to *host_out (use pinned memory) and, if
+ * reset != 0, a clear of the flag behind the copy; the value is valid once the caller has synchronised the
+ * stream.  The host side clears the flag at the start of a sampling run / decode and checks it at the end. */
+int t2h_split_overflow_async(int32_t* flag, int32_t* host_out, int32_t reset, void* stream);
 /* measurement hook (bench.py): the NEXT t2h_gemm_split_f32 launch of the calling thread records its own
  * start / end into the two hipEvent_t (hipExtLaunchKernelGGL: the kernel's timestamps, what rocprofv3's
  * kernel trace reports), then the hook disarms.  NULL, NULL disarms. */
@@ -169,20 +170,21 @@ int t2h_gemm_split_time_next_launch(void* start_event, void* stop_event);
 int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..3, 5, 6, 8 / 10 (ping-pong LDS-DMA, 256x128 / 128x192), 9 (few-rows kernel), -1 auto;
                                               thread-local: it affects launches of the calling thread only */
 /* fp32 [rows, C] (row stride ldx) -> split rows */
-int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream);
+int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, int32_t* overflow_flag,
+                       void* stream);
 /* producers that emit split rows directly: LayerNorm (transformer_arch.py:93-95)
  * and the attention output (transformer_arch.py:65-67) */
 int t2h_layernorm_split_f32(const float* x, const float* gamma, const float* beta, uint16_t* y_split,
-                            int32_t rows, int32_t C, float eps, void* stream);
+                            int32_t rows, int32_t C, float eps, int32_t* overflow_flag, void* stream);
 int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, int32_t T,
-                                int32_t n_head, void* stream);
+                                int32_t n_head, int32_t* overflow_flag, void* stream);
 /* the same attention (transformer_arch.py:52-67, causal=False, head dim 64) with both
  * matrix products as three fp16 partial products: q and k are read as split rows from qk_split
  * ([B*T][ld_cols/32][2][32], q at columns [0, C), k at [C, 2C), C = 64 n_head -- the C_split
  * output of the q|k|v projection) and v from the Vt planes the same projection wrote
  * (t2h_gemm_split_args.Vt); output as fp32 rows y [B*T, C] and / or split rows y_split. */
 int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,
-                      uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, void* stream);
+                      uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag, void* stream);
 
 /* ------------------------------------------------------ normalisation ------
  * LayerNorm over the last dim (eps 1e-5): transformer_arch.py:80-81,93-95,231,270 */

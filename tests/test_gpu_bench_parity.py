@@ -40,171 +40,111 @@ from oracle import torch_ref as R
 from text2human_amd import defaults, engine, options, synthetic
 from text2human_amd.models import SampleFromParsingModel
 
+from parity_util import ACT_TOL, DEV, account, forced_run, oracle_run, seed_all
+
 pytestmark = pytest.mark.gpu
-DEV = 'cuda'
 B, STEPS, SEED = 8, 256, 2021          # bench.py defaults (BASELINE.json configs[1])
-ACT_TOL = 2e-4                          # activations, on O(1) values
 OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
 
 
-class RecordingNoise(R.TorchNoise):
-    """TorchNoise that remembers the device generator state at the start of every step."""
-
-    def __init__(self, device):
-        super().__init__(device)
-        self.state = {}
-
-    def uniform(self, step, shape):
-        self.state[step] = torch.cuda.get_rng_state(self.device)
-        return super().uniform(step, shape)
-
-
-def _seed(s):
-    torch.manual_seed(s)
-    torch.cuda.manual_seed_all(s)
-
-
-def _oracle_run(model, sd_dev, batch):
-    noise, trace = RecordingNoise(DEV), []
-    _seed(SEED)
-    with torch.no_grad():
-        ref = R.sample_fn(model.segm_tokens, batch['texture_mask'].to(DEV), sd_dev, sample_steps=STEPS,
-                          noise=noise, trace=trace)
-    return ref, {d['t']: d for d in trace}, noise.state
-
-
-def _forced_run(model, trace, compact):
-    """HIP sampler on the oracle's trajectory; -> list of (t, row, ours, oracle's).
-
-    compact=False: one round per step, all samples at that step (the reference's loop).
-    compact=True (the default schedule of the product path): every sample walks through its OWN
-    active steps, so a round holds samples at different steps; sample b at step t must agree with --
-    and is then forced to -- the oracle's state of sample b after step t."""
-    mism = []
-    T = trace[STEPS]['x_t'].shape[1]
-
-    def step_hook(t, x_t, out):
-        want = trace[t]['x_t']
-        bad = (x_t != want).nonzero()
-        for b, j in bad.tolist():
-            mism.append((t, b * T + j, int(x_t[b, j]), int(want[b, j])))
-        x_t.copy_(want)
-
-    def round_hook(r, steps, x_t, out):
-        for b, t in enumerate(steps.tolist()):
-            if t == 0:
-                continue                                    # idle in this round: nothing was sampled
-            want = trace[t]['x_t'][b]
-            for j in (x_t[b] != want).nonzero().flatten().tolist():
-                mism.append((t, b * T + j, int(x_t[b, j]), int(want[j])))
-            x_t[b].copy_(want)
-
-    _seed(SEED)
-    tex_tok = model._texture_tokens(model.texture_mask)
-    kw = dict(round_hook=round_hook, compact=True) if compact else dict(step_hook=step_hook)
-    engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, STEPS, model.mask_id, **kw)
-    return mism, dict(model.sampler_fn.last_stats)
-
-
-def _account(model, sd_dev, batch, trace, rng_state, mism, scale):
-    """gap / dl of every mismatch (see module docstring)."""
-    rows = []
-    tex_tok = R.texture_tokens(batch['texture_mask'], (32, 16)).to(DEV)
-    n = tex_tok.numel()
-    for t, row, ours, theirs in mism:
-        prev = trace[t + 1]['x_t'] if t < STEPS else torch.full_like(trace[t]['x_t'], model.mask_id)
-        head = int(tex_tok.view(-1)[row])
-        with torch.no_grad():
-            lo = R.transformer_logits(prev, model.segm_tokens, tex_tok, sd_dev, heads={head})[head]
-        lm = model.sampler_fn.logits(prev, model.segm_tokens.contiguous(), tex_tok, heads={head})[head]
-        lo_r, lm_r = lo.reshape(n, -1)[row].double(), lm.reshape(n, -1)[row].double()
-        torch.cuda.set_rng_state(rng_state[t], DEV)
-        torch.rand((B, n // B), device=DEV)
-        expo = None
-        for cb in trace[t]['active']:
-            e = torch.empty((n, lo_r.numel()), device=DEV).exponential_(1.0)
-            if cb == head:
-                expo = e[row].double()
-        score = torch.log_softmax(lo_r, -1) - expo.log()
-        a, c = theirs - 1024 * head, ours - 1024 * head
-        rows.append(dict(step=t, row=row, head=head, ours=c, oracle=a,
-                         gap=float(score[a] - score[c]), dl=float((lo_r - lm_r).abs().max()),
-                         logit_range=float(lo_r.max() - lo_r.min())))
-    for r in rows:
-        r['explained'] = bool(r['gap'] <= 2.0 * r['dl'] + 1e-7 and r['dl'] <= ACT_TOL * scale)
-    return rows
-
-
-@pytest.mark.parametrize('peaked', [False, True], ids=['default_weights', 'peaked_logits_x50'])
-def test_bench_config_parity(peaked, monkeypatch):
+def _full_parity(batch_size, peaked, tag, all_paths=True):
+    """The whole sample_from_parsing path at `batch_size`, 256 steps, seed 2021 against the oracle:
+    tokenizer exact, sampler teacher-forced (every decision accounted for) and free-running, bottom
+    indices exact, image within ACT_TOL.  -> report dict (also written under gpurun_out/)."""
     scale = 50.0 if peaked else 1.0
     opt = options.dict_to_nonedict(defaults.sample_from_parsing())
     sds = synthetic.make_state_dicts(opt, seed=1234, head_scale=scale, argmax_scale=scale)
     sd_dev = {k: v.to(DEV) for k, v in sds['sampler'].items()}
-    batch = synthetic.parsing_batch(B, seed=SEED)
-    report = dict(config=f'B={B}, {STEPS} steps, seed {SEED}, head/argmax scale {scale:g}', paths={})
+    batch = synthetic.parsing_batch(batch_size, seed=SEED)
+    report = dict(config=f'B={batch_size}, {STEPS} steps, seed {SEED}, head/argmax scale {scale:g}', paths={})
 
     model = SampleFromParsingModel(opt, state_dicts=sds)  # default: split-precision sampler
     assert model.sampler_fn.split and model.sampler_fn.split_mha
     model.feed_data(batch)
-    ref, trace, rng_state = _oracle_run(model, sd_dev, batch)
+    with torch.no_grad():   # tokenizer on non-degenerate maps: exact against the CPU oracle at this batch size
+        tok_ref = R.segm_tokens(batch['segm'], sds['segm_encoder'], sds['segm_quant_conv'],
+                                sds['segm_quantizer']['embedding.weight']).view(batch_size, -1)
+    report['segm_token_mismatches'] = int((model.segm_tokens.cpu() != tok_ref).sum())
+    ref, trace, rng_state = oracle_run(model.segm_tokens, batch['texture_mask'], sd_dev, STEPS, SEED)
     ref_t = torch.stack(ref)
-    assert (ref_t >= 0).sum().item() == B * 512  # every token sampled exactly once
+    assert (ref_t >= 0).sum().item() == batch_size * 512  # every token sampled exactly once
 
     exact = engine.SamplerNet(model.P, model._tf_desc, opt['bert_n_head'], 'tf', split=False)
     split = model.sampler_fn
-    for name, net, compact in (('split_2xfp16', split, True), ('split_2xfp16_synchronous_steps', split, False),
-                               ('exact_fp32', exact, True)):
+    paths = [('split_2xfp16', split, True)]
+    if all_paths:
+        paths += [('split_2xfp16_synchronous_steps', split, False), ('exact_fp32', exact, True)]
+    for name, net, compact in paths:
         model.sampler_fn = net
-        mism, stats = _forced_run(model, trace, compact)
-        acc = _account(model, sd_dev, batch, trace, rng_state, mism, scale)
-        report['paths'][name] = dict(decisions=B * 512, mismatches=len(mism), accounted=acc, schedule=stats)
+        mism, stats = forced_run(model, trace, STEPS, SEED, compact)
+        acc = account(model, sd_dev, batch['texture_mask'], trace, rng_state, mism, STEPS, scale)
+        report['paths'][name] = dict(decisions=batch_size * 512, mismatches=len(mism), accounted=acc, schedule=stats)
     model.sampler_fn = split
     st = report['paths']['split_2xfp16']['schedule']
     # a (sample, step) pair is evaluated iff it changes a token; ~13.5 % of them change none
-    assert st['sample_steps_needed'] < 0.9 * st['sample_steps_possible'] and st['rounds'] < STEPS
-    assert report['paths']['split_2xfp16_synchronous_steps']['schedule']['rounds'] == len(
-        [t for t in trace if trace[t]['active']])
+    assert st['sample_steps_needed'] < 0.9 * st['sample_steps_possible']
+    if all_paths:
+        assert st['rounds'] < STEPS
+        assert report['paths']['split_2xfp16_synchronous_steps']['schedule']['rounds'] == len(
+            [t for t in trace if trace[t]['active']])
 
-    # free-running (not teacher-forced) runs of both product paths: what bench.py compares
+    # free-running (not teacher-forced) runs of the product paths: what bench.py times
     free = {}
-    for name, net in (('split_2xfp16', split), ('exact_fp32', exact)):
+    for name, net in (('split_2xfp16', split), ('exact_fp32', exact))[:2 if all_paths else 1]:
         model.sampler_fn = net
-        _seed(SEED)
+        seed_all(SEED)
         free[name] = torch.stack(model.sample_fn(temp=1, sample_steps=STEPS))
     model.sampler_fn = split
-    report['free_running'] = dict(
-        split_vs_exact_mismatches=int((free['split_2xfp16'] != free['exact_fp32']).sum()),
-        split_vs_oracle_mismatches=int((free['split_2xfp16'] != ref_t).sum()),
-        exact_vs_oracle_mismatches=int((free['exact_fp32'] != ref_t).sum()))
+    report['free_running'] = dict(split_vs_oracle_mismatches=int((free['split_2xfp16'] != ref_t).sum()))
+    if all_paths:
+        report['free_running'].update(
+            split_vs_exact_mismatches=int((free['split_2xfp16'] != free['exact_fp32']).sum()),
+            exact_vs_oracle_mismatches=int((free['exact_fp32'] != ref_t).sum()))
 
     # refine + decode on the oracle's tokens (oracle on the CPU: exact direct fp32 convolutions):
-    # bottom indices exact, image within tolerance
+    # bottom indices exact, image within tolerance -- every image of the batch
     with torch.no_grad():
         ref_img, inter = R.refine_and_decode([t.cpu() for t in ref], batch['texture_mask'], sds)
     img, _, inters = model.decode_indices(ref, want_u8=True, return_inter=True)
     bot = torch.cat([d['bot_lists'].view(18, -1, 32, 16) for d in inters], 1).cpu()
-    ref_bot = torch.stack(inter['bot_idx']).view(18, B, 32, 16)
-    bot_bad = int((bot != ref_bot).sum())
-    img_err = float((img.cpu() - ref_img).abs().max())
-    report['decode'] = dict(bot_index_mismatches=bot_bad, bot_indices=int((ref_bot >= 0).sum()),
-                            img_max_abs_err=img_err)
+    ref_bot = torch.stack(inter['bot_idx']).view(18, batch_size, 32, 16)
+    report['decode'] = dict(bot_index_mismatches=int((bot != ref_bot).sum()), bot_indices=int((ref_bot >= 0).sum()),
+                            img_max_abs_err=float((img.cpu() - ref_img).abs().max()), images=batch_size)
 
     os.makedirs(OUT_DIR, exist_ok=True)
-    with open(os.path.join(OUT_DIR, f'parity_bench_config_{"peaked" if peaked else "default"}.json'), 'w') as f:
+    with open(os.path.join(OUT_DIR, f'parity_{tag}.json'), 'w') as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report))
 
+    assert report['segm_token_mismatches'] == 0, report['segm_token_mismatches']
     for name, r in report['paths'].items():
         unexplained = [a for a in r['accounted'] if not a['explained']]
         assert not unexplained, f'{name}: {len(unexplained)} of {r["mismatches"]} mismatches are not float near-ties: {unexplained[:5]}'
+    assert report['decode']['bot_index_mismatches'] == 0, report['decode']
+    assert report['decode']['bot_indices'] == batch_size * 512, report['decode']
+    assert report['decode']['img_max_abs_err'] < ACT_TOL, report['decode']
+    return report
+
+
+@pytest.mark.parametrize('peaked', [False, True], ids=['default_weights', 'peaked_logits_x50'])
+def test_bench_config_parity(peaked):
+    report = _full_parity(B, peaked, 'bench_config_' + ('peaked' if peaked else 'default'))
     if not peaked:
         # near-uniform logits: the race is decided by the noise, no near-tie is expected at all
         assert report['paths']['split_2xfp16']['mismatches'] == 0, report['paths']['split_2xfp16']
         assert report['free_running']['split_vs_oracle_mismatches'] == 0, report['free_running']
         assert report['free_running']['split_vs_exact_mismatches'] == 0, report['free_running']
-    assert bot_bad == 0, report['decode']
-    assert img_err < ACT_TOL, report['decode']
+
+
+def test_parsing_batch_32_full_parity():
+    """BASELINE.json configs[3]'s per-GPU share (bench.py other_configs.parsing_b32): 32 parsing maps, ALL 256
+    sampling steps -- M = 16384 rows through every sampler Linear (the 256x128 / 128x128 dispatch, not the
+    headline's), attention over 32 x 8 heads, up to 256 changed rows per round in the sampling tail, 4 decode
+    chunks.  Teacher-forced 0 unexplained of 16384 decisions; free-running tokens == the eager-GPU oracle's;
+    bottom indices 16384 / 16384; all 32 images within tolerance."""
+    report = _full_parity(32, False, 'parsing_b32', all_paths=False)
+    assert report['paths']['split_2xfp16']['mismatches'] == 0, report['paths']['split_2xfp16']
+    assert report['free_running']['split_vs_oracle_mismatches'] == 0, report['free_running']
 
 
 def test_split_overflow_is_loud():

@@ -40,7 +40,7 @@ def test_q_sample_and_masked_ce_kernels():
     assert (samples.cpu().double() - ce.view(B, T).sum(1)).abs().max().item() < 2e-3
 
 
-@pytest.mark.parametrize('loss_type', ['reweighted_elbo', 'mlm'])
+@pytest.mark.parametrize('loss_type', ['reweighted_elbo', 'elbo', 'mlm'])
 def test_train_loss_matches_oracle(loss_type):
     from oracle import torch_ref as R
     opt = options.dict_to_nonedict(defaults.sample_from_parsing())

@@ -86,3 +86,13 @@ def test_padded_tables_repeat_a_row_of_the_same_round():
         assert (val_tbl[r] == rows_tbl[r].astype(np.int64) * 7 + 3).all()        # values travel with their rows
     with pytest.raises(ValueError):
         schedule.padded_tables(order, vals, start, widest - 1)
+
+
+def test_seed_as_int64_roundtrip():
+    """torch's initial_seed() is a uint64; the graph path keeps it in an int64 device word."""
+    import torch
+    for u in (0, 5, 2**63 - 1, 2**63, 2**64 - 3):
+        i = schedule.as_int64(u)
+        assert -2**63 <= i < 2**63 and (i & 0xFFFFFFFFFFFFFFFF) == u
+        t = torch.empty(1, dtype=torch.int64).fill_(i)      # (fill_(u) itself raises for u >= 2^63)
+        assert int(t.view(torch.uint8).numpy().view('<u8')[0]) == u

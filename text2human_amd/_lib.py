@@ -41,7 +41,7 @@ class GemmSplitArgs(ctypes.Structure):
     _fields_ = [
         ('A', c_vp), ('B', c_vp), ('C', c_vp), ('C_split', c_vp), ('bias', c_vp), ('residual', c_vp),
         ('M', c_i32), ('N', c_i32), ('K', c_i32), ('ldc', c_i32), ('ldr', c_i32), ('epi_act', c_i32),
-        ('Vt', c_vp), ('vt_col0', c_i32), ('vt_T', c_i32), ('vt_hd', c_i32),
+        ('Vt', c_vp), ('vt_col0', c_i32), ('vt_T', c_i32), ('vt_hd', c_i32), ('overflow_flag', c_vp),
     ]
 
 
@@ -69,17 +69,17 @@ SIGNATURES = {
     't2h_conv3x3_small_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32,
                                              c_i32, c_i32, c_vp]),
     't2h_conv_split_force_tile': (ctypes.c_int, [ctypes.c_int]),
-    't2h_split_overflow': (ctypes.c_int, [c_i32, c_vp]),
-    't2h_split_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i32, c_vp]),
-    't2h_layernorm_split_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
-    't2h_mha_noncausal_split_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    't2h_mha_split_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    't2h_split_overflow_async': (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp]),
+    't2h_split_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    't2h_layernorm_split_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp]),
+    't2h_mha_noncausal_split_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    't2h_mha_split_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     't2h_version': (ctypes.c_int, []),
     't2h_last_error': (ctypes.c_char_p, []),
     't2h_gemm_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp]),
     't2h_gemm_tile_config': (ctypes.c_int, [ctypes.POINTER(GemmArgs)]),
     't2h_conv_split_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp]),
-    't2h_gn_apply_split_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    't2h_gn_apply_split_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     't2h_gemm_force_config': (ctypes.c_int, [ctypes.c_int]),
     't2h_layernorm_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
     't2h_groupnorm_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32]),

@@ -15,43 +15,17 @@ void t2h_set_error(const char* fmt, ...) {
 extern "C" int t2h_version(void) { return 100; }
 extern "C" const char* t2h_last_error(void) { return g_err; }
 
-// ---- sticky overflow flag of the split-precision producers (common.h): one word per
-// (device, stream) ----
-#include <mutex>
-#include <vector>
-
-namespace {
-struct OvfSlot {
-  int dev;
-  void* stream;
-  int* flag;
-};
-std::vector<OvfSlot> g_ovf;
-std::mutex g_ovf_mu;
-}  // namespace
-
-int* t2h_split_overflow_flag_ptr(void* stream) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(g_ovf_mu);
-  for (const OvfSlot& s : g_ovf)
-    if (s.dev == dev && s.stream == stream) return s.flag;
-  int* p = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(int)) != hipSuccess) return nullptr;
-  if (hipMemset(p, 0, sizeof(int)) != hipSuccess) return nullptr;
-  g_ovf.push_back(OvfSlot{dev, stream, p});
-  return p;
-}
-
-extern "C" int t2h_split_overflow(int32_t reset, void* stream) {
-  int* p = t2h_split_overflow_flag_ptr(stream);
-  T2H_REQUIRE(p != nullptr, "t2h_split_overflow: cannot allocate the device flag");
+// ---- sticky overflow flag of the split-precision producers (common.h): the word belongs to the caller.
+// Enqueues, on `stream`, a copy of *flag to *host_out (pinned host memory for a truly asynchronous copy) and,
+// if reset != 0, a clear of the flag behind it.  Does not synchronise: the value is valid once the caller has
+// synchronised the stream (or an event recorded after this call).
+extern "C" int t2h_split_overflow_async(int32_t* flag, int32_t* host_out, int32_t reset, void* stream) {
+  T2H_REQUIRE(flag != nullptr && (host_out != nullptr || reset), "t2h_split_overflow_async: NULL pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int v = 0;
-  if (hipMemcpyAsync(&v, p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-      (reset && hipMemsetAsync(p, 0, sizeof(int), s) != hipSuccess) || hipStreamSynchronize(s) != hipSuccess) {
-    t2h_set_error("t2h_split_overflow: %s", hipGetErrorString(hipGetLastError()));
+  if ((host_out && hipMemcpyAsync(host_out, flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) ||
+      (reset && hipMemsetAsync(flag, 0, sizeof(int32_t), s) != hipSuccess)) {
+    t2h_set_error("t2h_split_overflow_async: %s", hipGetErrorString(hipGetLastError()));
     return T2H_ERR_LAUNCH;
   }
-  return v != 0 ? 1 : 0;
+  return T2H_OK;
 }

@@ -586,15 +586,15 @@ extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int3
 }
 
 extern "C" int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, int32_t T,
-                                           int32_t n_head, void* stream) {
+                                           int32_t n_head, int32_t* overflow_flag, void* stream) {
   T2H_REQUIRE(qkv && y_split, "t2h_mha_noncausal_split_f32: NULL pointer");
   T2H_REQUIRE(B > 0 && n_head > 0, "t2h_mha_noncausal_split_f32: empty problem");
   T2H_REQUIRE(T > 0 && T % QB == 0, "t2h_mha_noncausal_split_f32: T=%d must be a multiple of %d", T, QB);
   T2H_REQUIRE(t2h_aligned16(qkv) && t2h_aligned16(y_split), "t2h_mha_noncausal_split_f32: 16-byte alignment");
   const int C = n_head * HD;
   dim3 grid((T / QB) * n_head * B), block(512);
-  int* ovf = t2h_split_overflow_flag_ptr(stream);
-  T2H_REQUIRE(ovf != nullptr, "t2h_mha_noncausal_split_f32: no overflow flag");
+  int* ovf = overflow_flag;
+  T2H_REQUIRE(ovf != nullptr, "t2h_mha_noncausal_split_f32: overflow_flag is NULL");
   hipLaunchKernelGGL(mha_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qkv,
                      static_cast<float*>(nullptr), T, C, n_head, y_split, ovf);
   T2H_CHECK_LAUNCH("t2h_mha_noncausal_split_f32");
@@ -602,7 +602,8 @@ extern "C" int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, 
 }
 
 extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,
-                                 uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, void* stream) {
+                                 uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag,
+                                 void* stream) {
   T2H_REQUIRE(qk_split && vt && (y || y_split), "t2h_mha_split_f32: NULL pointer");
   T2H_REQUIRE(B > 0 && n_head > 0, "t2h_mha_split_f32: empty problem");
   T2H_REQUIRE(T > 0 && T % QB == 0, "t2h_mha_split_f32: T=%d must be a multiple of %d", T, QB);
@@ -613,8 +614,8 @@ extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, cons
                   (!y_split || t2h_aligned16(y_split)),
               "t2h_mha_split_f32: 16-byte alignment");
   dim3 grid((T / QB) * n_head * B), block(512);
-  int* ovf = t2h_split_overflow_flag_ptr(stream);
-  T2H_REQUIRE(ovf != nullptr, "t2h_mha_split_f32: no overflow flag");
+  int* ovf = overflow_flag;
+  T2H_REQUIRE(ovf != nullptr || y_split == nullptr, "t2h_mha_split_f32: overflow_flag is NULL (needed with y_split)");
   hipLaunchKernelGGL(mha_split_pipe_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt, y,
                      y_split, T, C, n_head, ovf);
   T2H_CHECK_LAUNCH("t2h_mha_split_f32");

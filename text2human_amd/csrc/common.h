@@ -11,13 +11,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void t2h_set_error(const char* fmt, ...);
 
-// Device-resident sticky flag of the split-precision producers (api.hip): set when a value
-// that is about to be written as split rows does not fit fp16's range (|x| >= 65504 would
-// turn into inf / NaN planes).  Read back by t2h_split_overflow().  One word per (device,
-// stream), allocated the first time a stream is seen, so that two models driven on two
-// streams neither share nor clear each other's flag; NULL only if that allocation failed
-// (reported by the caller).
-int* t2h_split_overflow_flag_ptr(void* stream);
+// Sticky overflow flag of the split-precision producers: ONE int32 word in device memory that the CALLER
+// owns and passes to every producer of split rows (t2h_gemm_split_args.overflow_flag, the overflow_flag
+// argument of the LayerNorm / GroupNorm-apply / attention / split_rows entry points).  A producer sets it
+// when a value that is about to be written as split rows does not fit fp16's range (|x| >= 65504 would turn
+// into inf / NaN planes).  The library neither allocates nor reads it back (t2h_split_overflow_async only
+// enqueues the copy).
 
 #define T2H_REQUIRE(cond, ...)                 \
   do {                                         \

@@ -698,8 +698,7 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE((int64_t)(a.M > a.N ? a.M : a.N) * a.K * 4 < (int64_t(1) << 31),
               "t2h_gemm_split_f32: operands are addressed with 32-bit byte offsets (each must span < 2 GiB)");
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
-  int* ovf = t2h_split_overflow_flag_ptr(s);
-  T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
+  int* ovf = a.overflow_flag;
   launch_maybe_timed(gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP>, grid, dim3(64 * WARPS_M * WARPS_N * KS), s, a,
                      ovf);
   T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
@@ -729,6 +728,11 @@ extern "C" int t2h_gemm_split_force_config(int cfg) {
 }
 
 extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream) {
+  // the timing hook is for THIS call: a call that fails a check before it launches must not leave the events
+  // armed for a later, unrelated launch
+  struct Disarm {
+    ~Disarm() { g_time_start = g_time_stop = nullptr; }
+  } disarm_on_exit;
   T2H_REQUIRE(args != nullptr, "t2h_gemm_split_f32: args is NULL");
   const t2h_gemm_split_args a = *args;
   T2H_REQUIRE(a.A && a.B && (a.C || a.C_split || a.Vt), "t2h_gemm_split_f32: NULL operand");
@@ -739,6 +743,8 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
                   (!a.residual || (a.ldr % 4 == 0 && t2h_aligned16(a.residual))),
               "t2h_gemm_split_f32: N must be a multiple of 8, ldc / ldr of 4, C / residual 16-byte aligned");
   if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
+  T2H_REQUIRE(a.overflow_flag != nullptr || (!a.C_split && !a.Vt),
+              "t2h_gemm_split_f32: overflow_flag is NULL (needed with C_split / Vt outputs)");
   if (a.Vt)
     T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 128 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&
                     a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,
@@ -777,8 +783,7 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
   if (g_force_split_cfg < 0 && a.M <= 64 && skinny_ok) cfg = 9;
   if (cfg == 9) {
     T2H_REQUIRE(skinny_ok, "t2h_gemm_split_f32: the few-rows kernel needs N %% 16 == 0 and no Vt routing");
-    int* ovf = t2h_split_overflow_flag_ptr(s);
-    T2H_REQUIRE(ovf != nullptr, "t2h_gemm_split_f32: no overflow flag");
+    int* ovf = a.overflow_flag;
     launch_maybe_timed(gemm_split_skinny_kernel, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), s, a, ovf);
     T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
     return T2H_OK;
@@ -795,11 +800,12 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
   }
 }
 
-extern "C" int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, void* stream) {
+extern "C" int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C,
+                                  int32_t* overflow_flag, void* stream) {
   T2H_REQUIRE(x && out && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0, "t2h_split_rows_f32: bad arguments");
   const int64_t total = rows * (C / 4);
-  int* ovf = t2h_split_overflow_flag_ptr(stream);
-  T2H_REQUIRE(ovf != nullptr, "t2h_split_rows_f32: no overflow flag");
+  int* ovf = overflow_flag;
+  T2H_REQUIRE(ovf != nullptr, "t2h_split_rows_f32: overflow_flag is NULL");
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ldx, out, total, C, ovf);
   T2H_CHECK_LAUNCH("t2h_split_rows_f32");

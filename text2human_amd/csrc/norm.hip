@@ -170,11 +170,12 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_finalize_kernel(const double* 
   __shared__ double cs[GNF_THREADS], css[GNF_THREADS];
   __shared__ float g_stat[2];
   const int g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
-  const int cpg = C / groups;              // host: cpg divides 256
-  const int slices = GNF_THREADS / cpg;
+  const int cpg = C / groups;              // host: cpg <= 256
+  const int slices = GNF_THREADS / cpg;    // whole slices; when cpg does not divide 256 (a checkpoint with ch = 96:
+                                           // cpg = 3, 6, 12) the threads beyond slices * cpg stay idle and add zeros
   const int ch = tid % cpg, sl = tid / cpg;
   const int per = (chunks + slices - 1) / slices;
-  const int k0 = sl * per, k1 = min(chunks, k0 + per);
+  const int k0 = sl < slices ? sl * per : chunks, k1 = min(chunks, k0 + per);
   const double* p = part + ((int64_t)img * chunks * 2) * C + g * cpg + ch;
   double s = 0, ss = 0;
   int k = k0;
@@ -275,7 +276,7 @@ extern "C" int t2h_layernorm_f32(const float* x, const float* gamma, const float
 
 extern "C" int t2h_layernorm_split_f32(const float* x, const float* gamma, const float* beta,
                                        uint16_t* y_split, int32_t rows, int32_t C, float eps,
-                                       void* stream) {
+                                       int32_t* overflow_flag, void* stream) {
   T2H_REQUIRE(x && gamma && beta && y_split, "t2h_layernorm_split_f32: NULL pointer");
   T2H_REQUIRE(rows > 0, "t2h_layernorm_split_f32: rows=%d", rows);
   T2H_REQUIRE(t2h_aligned16(x) && t2h_aligned16(y_split) && t2h_aligned16(gamma) && t2h_aligned16(beta),
@@ -283,8 +284,8 @@ extern "C" int t2h_layernorm_split_f32(const float* x, const float* gamma, const
   dim3 grid((rows + T2H_LN_RPB - 1) / T2H_LN_RPB), block(64 * T2H_LN_RPB);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* y = reinterpret_cast<float*>(y_split);
-  int* ovf = t2h_split_overflow_flag_ptr(stream);
-  T2H_REQUIRE(ovf != nullptr, "t2h_layernorm_split_f32: no overflow flag");
+  int* ovf = overflow_flag;
+  T2H_REQUIRE(ovf != nullptr, "t2h_layernorm_split_f32: overflow_flag is NULL");
   if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
   else if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
   else if (C == 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
@@ -310,8 +311,8 @@ extern "C" int t2h_groupnorm_tables_f32(const float* x, int32_t ldx, const float
   T2H_REQUIRE(n_img > 0 && HW > 0, "t2h_groupnorm_tables_f32: empty problem");
   T2H_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && C / 4 <= 256,
               "t2h_groupnorm_tables_f32: C=%d unsupported", C);
-  T2H_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0 && GNF_THREADS % (C / groups) == 0,
-              "t2h_groupnorm_tables_f32: groups=%d (C / groups must divide 256)", groups);
+  T2H_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0 && C / groups <= GNF_THREADS,
+              "t2h_groupnorm_tables_f32: groups=%d (C / groups must be <= 256)", groups);
   T2H_REQUIRE(ldx % 4 == 0 && t2h_aligned16(x), "t2h_groupnorm_tables_f32: alignment");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int chunks = gn_chunks(HW);
@@ -329,8 +330,8 @@ extern "C" int t2h_groupnorm_finalize_f32(const double* part, int32_t chunks, co
                                           int32_t groups, float eps, void* stream) {
   T2H_REQUIRE(part && gamma && beta && scale && shift, "t2h_groupnorm_finalize_f32: NULL pointer");
   T2H_REQUIRE(n_img > 0 && HW > 0 && chunks > 0 && C > 0 && C <= 1024 && groups > 0 && groups <= 64 && C % groups == 0 &&
-                  GNF_THREADS % (C / groups) == 0,
-              "t2h_groupnorm_finalize_f32: bad shape (C <= 1024, groups <= 64, C / groups divides 256)");
+                  C / groups <= GNF_THREADS,
+              "t2h_groupnorm_finalize_f32: bad shape (C <= 1024, groups <= 64, C / groups <= 256)");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_img), dim3(GNF_THREADS), 0, static_cast<hipStream_t>(stream),
                      part, chunks, HW, C, groups, eps, gamma, beta, scale, shift);
   T2H_CHECK_LAUNCH("t2h_groupnorm_finalize_f32");
@@ -355,7 +356,7 @@ extern "C" int t2h_softmax_rows_f32(float* x, int32_t rows, int32_t n, int32_t l
 
 extern "C" int t2h_gn_apply_split_f32(const float* x, int32_t ldx, const float* scale, const float* shift,
                                       int32_t tbl_ld, uint16_t* out_split, int64_t rows, int32_t rows_per_img,
-                                      int32_t C, int32_t act, void* stream) {
+                                      int32_t C, int32_t act, int32_t* overflow_flag, void* stream) {
   T2H_REQUIRE(x && out_split && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0 && t2h_aligned16(x) &&
                   t2h_aligned16(out_split),
               "t2h_gn_apply_split_f32: bad arguments (C %% 32, ldx %% 4, 16-byte alignment)");
@@ -364,8 +365,8 @@ extern "C" int t2h_gn_apply_split_f32(const float* x, int32_t ldx, const float* 
   if (scale)
     T2H_REQUIRE(rows_per_img > 0 && tbl_ld % 4 == 0 && t2h_aligned16(scale) && t2h_aligned16(shift),
                 "t2h_gn_apply_split_f32: tables");
-  int* ovf = t2h_split_overflow_flag_ptr(stream);
-  T2H_REQUIRE(ovf != nullptr, "t2h_gn_apply_split_f32: no overflow flag");
+  int* ovf = overflow_flag;
+  T2H_REQUIRE(ovf != nullptr, "t2h_gn_apply_split_f32: overflow_flag is NULL");
   const int64_t total = rows * (C / 8);
   hipLaunchKernelGGL(gn_apply_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ldx, scale, shift, tbl_ld, rows_per_img > 0 ? rows_per_img : 1,

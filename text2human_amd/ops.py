@@ -23,6 +23,37 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- the sticky overflow word of the split-row producers (include/t2h_hip.h): owned HERE, one int32 in
+# device memory per (device, stream) plus a pinned host word the asynchronous read-back lands in.  Models
+# driven on different streams (or threads, each on its own stream) neither see nor clear each other's flag.
+_ovf_slots = {}
+
+
+def _ovf_slot():
+    dev = torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    slot = _ovf_slots.get(key)
+    if slot is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.T2HError('the overflow flag of this stream must exist before a capture begins: call '
+                                'ops.split_overflow(reset=True) on the stream first')
+        slot = _ovf_slots[key] = (torch.zeros(1, dtype=torch.int32, device=f'cuda:{dev}'),
+                                  torch.zeros(1, dtype=torch.int32).pin_memory())
+    return slot
+
+
+def overflow_flag():
+    """Device pointer of the current stream's overflow word (allocated, zeroed, at first use)."""
+    return ctypes.c_void_p(_ovf_slot()[0].data_ptr())
+
+
+def release_overflow_flag(stream=None):
+    """Forgets the overflow word of `stream` (default: the current one), e.g. before the stream is destroyed:
+    a later stream that reuses the handle then starts from a fresh, zeroed word."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    _ovf_slots.pop((torch.cuda.current_device(), st.cuda_stream), None)
+
+
 def _chk_f32(*ts):
     for t in ts:
         if t is None:
@@ -168,7 +199,7 @@ def gn_apply_split(x, scale=None, shift=None, rows_per_img=0, act=PRO_NONE, out=
         out = split_rows_empty(rows, C, x.device)
     check(_lib.load().t2h_gn_apply_split_f32(_p(x), _rows(x), _p(scale), _p(shift),
                                              scale.shape[1] if scale is not None else 0, _p(out), rows,
-                                             rows_per_img, C, act, _stream()), 't2h_gn_apply_split_f32')
+                                             rows_per_img, C, act, overflow_flag(), _stream()), 't2h_gn_apply_split_f32')
     return out
 
 
@@ -325,7 +356,8 @@ def split_rows(x, out=None):
     rows, C = x.shape
     if out is None:
         out = split_rows_empty(rows, C, x.device)
-    check(_lib.load().t2h_split_rows_f32(_p(x), _rows(x), _p(out), rows, C, _stream()), 't2h_split_rows_f32')
+    check(_lib.load().t2h_split_rows_f32(_p(x), _rows(x), _p(out), rows, C, overflow_flag(), _stream()),
+          't2h_split_rows_f32')
     return out
 
 
@@ -357,6 +389,8 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     g.epi_act = act
     if vt is not None:
         g.Vt, g.vt_col0, g.vt_T, g.vt_hd = vt.data_ptr(), vt_col0, vt_T, vt_hd
+    if out_split is not None or vt is not None:
+        g.overflow_flag = _ovf_slot()[0].data_ptr()
     lib = _lib.load()
     if _prof is not None:
         _prof['count'] += 1
@@ -386,13 +420,21 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
     return out if out is not None else out_split
 
 
+def split_overflow_async(reset=True):
+    """Enqueues the read-back (and optional clear) of the current stream's overflow word; -> the pinned host
+    tensor the value lands in, valid once the stream has been synchronised.  No host wait here."""
+    flag, host = _ovf_slot()
+    check(_lib.load().t2h_split_overflow_async(_p(flag), _p(host), int(bool(reset)), _stream()), 't2h_split_overflow_async')
+    return host
+
+
 def split_overflow(reset=True):
-    """True if any split-row producer met a value outside fp16's range (|x| >= 65504) since
-    the last reset (sticky device flag, include/t2h_hip.h); synchronises the current stream."""
-    r = _lib.load().t2h_split_overflow(int(bool(reset)), _stream())
-    if r < 0:
-        check(r, 't2h_split_overflow')
-    return bool(r)
+    """True if any split-row producer launched on the current stream met a value outside fp16's range
+    (|x| >= 65504) since the last reset (sticky device word, include/t2h_hip.h).  Synchronises the current
+    stream -- here, in the host code, not inside the library."""
+    host = split_overflow_async(reset)
+    torch.cuda.current_stream().synchronize()
+    return bool(int(host[0]))
 
 
 def vt_empty(B, n_head, T, device, hd=64):
@@ -413,7 +455,7 @@ def mha_split(qk_split, ld_cols, vt, B, T, n_head, out=None, out_split=None):
     _chk_f32(out)
     check(_lib.load().t2h_mha_split_f32(_p(qk_split), ld_cols, _p(vt), _p(out) if out is not None else None,
                                         _p(out_split) if out_split is not None else None, B, T, n_head,
-                                        _stream()), 't2h_mha_split_f32')
+                                        overflow_flag() if out_split is not None else None, _stream()), 't2h_mha_split_f32')
     return out if out is not None else out_split
 
 
@@ -423,7 +465,7 @@ def layernorm_split(x, gamma, beta, out_split, eps=1e-5):
     assert x.is_contiguous()
     rows, C = x.shape
     check(_lib.load().t2h_layernorm_split_f32(_p(x), _p(gamma), _p(beta), _p(out_split), rows, C, eps,
-                                              _stream()), 't2h_layernorm_split_f32')
+                                              overflow_flag(), _stream()), 't2h_layernorm_split_f32')
     return out_split
 
 
@@ -431,7 +473,7 @@ def mha_noncausal_split(qkv, B, T, n_head, out_split):
     """Attention whose output is written as split rows."""
     _chk_f32(qkv)
     assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * n_head * 64)
-    check(_lib.load().t2h_mha_noncausal_split_f32(_p(qkv), _p(out_split), B, T, n_head, _stream()),
+    check(_lib.load().t2h_mha_noncausal_split_f32(_p(qkv), _p(out_split), B, T, n_head, overflow_flag(), _stream()),
           't2h_mha_noncausal_split_f32')
     return out_split
 

@@ -13,12 +13,20 @@ consequences, both used by engine.sample_tokens:
 * a sample whose tokens do not change at a step never has its logits read there, its `x_t` does
   not move, and samples never interact (attention is per sample): every sample can walk through
   ITS OWN active steps.  Round r evaluates, for every sample, its r-th active step -- about
-  0.865 * steps rounds of the full batch instead of `steps`, with bit-identical tokens.
+  0.865 * steps rounds of the full batch instead of `steps`, with the same tokens (up to fp32
+  summation-order ties in the last layer's few-rows tail, whose tile depends on the row count).
 
 This module is host-side integer bookkeeping (numpy); the draws themselves are reproduced on the
 device (t2h_unmask_schedule / t2h_sample_heads) or taken from an explicit noise source.
 """
 import numpy as np
+
+
+def as_int64(u64):
+    """A uint64 (torch's `initial_seed()` after `torch.seed()` / a negative `manual_seed`) as the int64 with the
+    same bits: what an int64 device tensor can hold; the kernels read the word back as uint64."""
+    u = int(u64) & 0xFFFFFFFFFFFFFFFF
+    return u - (1 << 64) if u >= (1 << 63) else u
 
 
 def draw_offsets(head_mask, steps, offset0, rand_inc, expo_inc, n_heads):

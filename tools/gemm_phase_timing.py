@@ -47,6 +47,8 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
     else:
         g.C_split = osp.data_ptr()
     g.epi_act = 1 if gelu else 0
+    ovf = torch.zeros(1, dtype=torch.int32, device='cuda')
+    g.overflow_flag = ovf.data_ptr()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for cfg in CFGS:
         lib.t2h_gemm_split_force_config(cfg)
