@@ -93,7 +93,9 @@ def parse_args(argv=None):
     ap.add_argument('--exact-steps', type=int, default=3)
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the "other_configs" legs (configs[3] per-GPU share, pose B=32, hires B=8) of the default run')
-    ap.add_argument('--no-graph-leg', action='store_true', help='skip the T2H_GRAPH=1 (graph replay) timing leg')
+    ap.add_argument('--no-eager-leg', action='store_true',
+                    help='skip the individual-launches leg (T2H_GRAPH=0 + HIP-event sampling of the GEMM launches) '
+                         'that the roofline object comes from')
     ap.add_argument('--other-steps', type=int, default=2, help='timed steps of each other_configs leg (after 1 warm-up)')
     ap.add_argument('--eager-gpu-baseline', action='store_true',
                     help='also time the oracle sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
@@ -391,17 +393,15 @@ class ConfigRun:
         return top, u8
 
     def timed(self, steps, warmup, dworld, dev):
-        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides;
-        returns the max-over-ranks time and this rank's stage / GEMM samples."""
+        """`warmup` untimed steps, then exactly `steps` steps of the DEFAULT product path (every sampling round
+        one hipGraph replay; no per-launch instrumentation) between barrier + synchronize on both sides;
+        returns the max-over-ranks time and this rank's stage samples."""
         from text2human_amd import shard
         sync = (lambda: None) if self.stub else torch.cuda.synchronize
         for _ in range(warmup):
             self.step()
         shard.barrier(dworld)
         sync()
-        if not self.stub:
-            from text2human_amd import ops
-            ops.gemm_profile_start(every=37)  # HIP-event pairs around a sample of GEMM launches
         events = []
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -410,12 +410,44 @@ class ConfigRun:
         my_elapsed = time.perf_counter() - t0
         shard.barrier(dworld)
         elapsed = shard.max_over_ranks(time.perf_counter() - t0, dworld, dev)
-        prof = {} if self.stub else ops.gemm_profile_stop()
         stage_ms = {}
         for name, e0, e1 in events:
             stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / steps
-        stats = getattr(getattr(self.model, 'sampler_fn', None), 'last_stats', None)
-        return dict(elapsed=elapsed, my_elapsed=my_elapsed, top=top, u8=u8, prof=prof, stage_ms=stage_ms, stats=stats)
+        net = getattr(self.model, 'sampler_fn', None)
+        return dict(elapsed=elapsed, my_elapsed=my_elapsed, top=top, u8=u8, stage_ms=stage_ms,
+                    stats=getattr(net, 'last_stats', None), launch_mode=getattr(net, 'last_launch_mode', None))
+
+    def eager_profile(self, steps):
+        """The SAME step as individual launches from the host thread (T2H_GRAPH=0) with the HIP-event sampling of
+        the GEMM launches armed (every 37th launch: events that receive the kernel's own start / end, and stream
+        intervals on other launches): the source of the `roofline` object, kept OUT of the headline's timed
+        region.  No collective in here (every rank may run it on its own).  -> dict(ms_per_step, prof, top, u8,
+        host_calls_per_round)."""
+        from text2human_amd import _lib, ops
+        old = os.environ.get('T2H_GRAPH')
+        os.environ['T2H_GRAPH'] = '0'
+        try:
+            self.step()  # (buffers / caches of the eager path)
+            torch.cuda.synchronize()
+            ops.gemm_profile_start(every=37)
+            t0 = time.perf_counter()
+            calls = []
+            for _ in range(steps):
+                self.set_seed(2021)
+                c0 = _lib.n_calls
+                top, u8 = self.step()
+                calls.append(_lib.n_calls - c0)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            prof = ops.gemm_profile_stop()
+        finally:
+            if old is None:
+                os.environ.pop('T2H_GRAPH', None)
+            else:
+                os.environ['T2H_GRAPH'] = old
+        stats = getattr(getattr(self.model, 'sampler_fn', None), 'last_stats', None) or {}
+        return dict(ms_per_step=1000.0 * dt, prof=prof, top=top, u8=u8,
+                    host_calls_per_step=calls[-1], rounds=stats.get('rounds'))
 
 
 def stage_view(stage_ms, b, sample_steps, upscale, stats):
@@ -461,18 +493,22 @@ def stage_view(stage_ms, b, sample_steps, upscale, stats):
     return st
 
 
-def side_config(name, run, steps, warmup, batch_per_gpu, world, dworld, dev):
+def side_config(name, run, steps, warmup, batch_per_gpu, world, dworld, dev, profile=True):
     """A further BASELINE.json configuration timed inside the same driver-run command (1 warm-up + 2
     steps by default): its own value, stages and dominant-kernel roofline."""
     r = run.timed(steps, warmup, dworld, dev)
     wl = WORKLOADS[name]
     out = {'metric': wl['metric'], 'value': batch_per_gpu * world * steps / r['elapsed'], 'unit': 'images/s',
            'ms_per_step': 1000.0 * r['elapsed'] / steps, 'steps': steps, 'warmup': warmup,
+           'launch_mode': r['launch_mode'],
            'config': {'workload': f'{wl["desc"]}, batch={batch_per_gpu}/GPU, {run.sample_steps} sampling steps ({wl["ref"]})',
                       'global_batch': batch_per_gpu * world},
            'stages': stage_view(r['stage_ms'], batch_per_gpu, run.sample_steps, run.upscale, r['stats'])}
-    if r['prof']:
-        out['roofline'] = gemm_roofline(r['prof'], name)
+    if not run.stub and profile:
+        e = run.eager_profile(1)
+        if e['prof']:
+            out['roofline'] = gemm_roofline(e['prof'], name)
+        out['eager_launches_ms_per_step'] = e['ms_per_step']
     return out
 
 
@@ -546,6 +582,11 @@ def main(argv=None):
     hw = (1024, 512) if run.upscale else (512, 256)
     assert tuple(u8.shape) == (n_mine, hw[0], hw[1], 3), tuple(u8.shape)
     per_rank_ms = shard.gather_floats(1000.0 * res['my_elapsed'] / args.steps, dworld, dev)
+    # ---- the same step as individual launches, with the per-launch event sampling armed (outside the headline's
+    # timed region, no collective: every rank runs it on its own)
+    eager = None
+    if not stub and not args.no_eager_leg:
+        eager = run.eager_profile(max(1, args.other_steps))
     # a checksum of every rank's images reaches rank 0 (the optional image gather of SURVEY 8(e))
     sums = shard.gather_floats(float(u8.to(torch.float64).sum()), dworld, dev)
 
@@ -624,8 +665,25 @@ def main(argv=None):
         return
 
     # ---- roofline of the dominant kernel = the GEMM instantiation with the largest sampled time
-    if res['prof']:
-        out['roofline'] = gemm_roofline(res['prof'], args.config)
+    out['launch_mode'] = {
+        'graph': 'hipGraph replay: ONE host launch per sampling round (engine.RoundGraph, the product default)',
+        'eager': 'individual launches from the host thread'}.get(res['launch_mode'], res['launch_mode'])
+    if eager is not None:
+        if eager['prof']:
+            out['roofline'] = gemm_roofline(eager['prof'], args.config)
+            out['roofline']['measured_in'] = ('the eager_launches leg of this command (same step, same kernels, individual '
+                                              'launches): per-launch events cannot be attached to the nodes of a replayed graph')
+        rounds = eager['rounds'] or 1
+        out['eager_launches'] = {
+            'value': batch_per_gpu * world / (eager['ms_per_step'] * 1e-3), 'unit': 'images/s (this rank x world)',
+            'ms_per_step': eager['ms_per_step'],
+            'tokens_equal': bool(torch.equal(torch.stack(eager['top']), torch.stack(top))),
+            'images_u8_equal': bool(torch.equal(eager['u8'], u8)),
+            'host_calls_per_step': eager['host_calls_per_step'],
+            'host_calls_per_round': eager['host_calls_per_step'] / rounds,
+            'note': f'T2H_GRAPH=0 with the GEMM event sampling armed, 1 warm-up + {max(1, args.other_steps)} steps; the headline '
+                    'issues 1 graph launch per round instead'}
+        out['host_launches_per_round'] = 1 if res['launch_mode'] == 'graph' else eager['host_calls_per_step'] / rounds
     # ---- stage view (HIP events on the launch stream), incl. decode's compute AND HBM fractions
     if res['stage_ms']:
         out['stages'] = stage_view(res['stage_ms'], batch_per_gpu, args.sample_steps, run.upscale, res['stats'])
@@ -679,24 +737,6 @@ def main(argv=None):
             'images_u8_equal': bool(int(diff.max()) == 0), 'img_u8_max_abs': int(diff.max()),
             'img_u8_frac_differing': float((diff != 0).float().mean()),
         }
-    if world == 1 and not args.no_graph_leg:
-        # the same step with every sampling round replayed from ONE captured hipGraph (T2H_GRAPH=1) instead of
-        # ~180 launches per round from the host thread: same kernels, same tokens (tests/test_gpu_edge_cases.py)
-        os.environ['T2H_GRAPH'] = '1'
-        try:
-            run.step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.other_steps):
-                top_g, u8_g = run.step()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / args.other_steps
-        finally:
-            os.environ.pop('T2H_GRAPH', None)
-        out['graph_replay'] = {'value': batch_per_gpu / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt,
-                               'tokens_equal': bool(torch.equal(torch.stack(top_g), torch.stack(top))),
-                               'images_u8_equal': bool(torch.equal(u8_g, u8)),
-                               'note': f'T2H_GRAPH=1 (opt-in), 1 capture / warm-up step + {args.other_steps} timed steps'}
     if world == 1 and args.eager_gpu_baseline:
         out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, 16, dev)
     print(json.dumps(out), flush=True)

@@ -125,3 +125,24 @@ def vq_mismatch_accounting(z_hip, z_ref, codebook, tok_hip, tok_ref):
         out.append(dict(row=row, ours=c, oracle=a, gap=dc - da, bound=bound, latent_err=float(e.abs().max()),
                         explained=bool(dc - da <= bound)))
     return out
+
+
+def balanced_pose_state_dicts(sds, opt, n=2, seed=99):
+    """Synthetic sample_from_pose weights whose parsing generator gives NON-degenerate maps.
+
+    With plain random weights the 24 class logits of the FCNHead differ by ~0.1 in their means and by
+    ~1e-3 over space, so every pose maps to one constant class -- and a constant map is an ill-conditioned
+    input for the tokenizer (GroupNorm of a constant plane amplifies rounding differences by orders of
+    magnitude: 1e-2 latent differences between two correct fp32 implementations).  Here the head's bias is
+    re-centred so that the class means are equal on a small calibration batch (the CPU oracle computes
+    them): the argmax is then decided by the spatial variation and the map has all 24 classes.  Returns a
+    shallow copy of `sds` with a new 'shape_decoder'."""
+    from text2human_amd import synthetic
+    pb = synthetic.pose_batch(n, seed=seed)
+    with torch.no_grad():
+        _, logits = R.parsing_from_pose(pb['densepose'], pb['shape_attr'], sds['shape_embedder'], sds['shape_encoder'],
+                                        sds['shape_decoder'], opt['shape_attr_class_num'])
+    out = dict(sds)
+    out['shape_decoder'] = dict(sds['shape_decoder'])
+    out['shape_decoder']['conv_seg.bias'] = sds['shape_decoder']['conv_seg.bias'] - logits.mean((0, 2, 3))
+    return out

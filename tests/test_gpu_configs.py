@@ -99,16 +99,22 @@ def test_upscaled_hierarchy_1024x512(model, sds):
 
 
 def test_sample_from_pose_batch_32_teacher_forced(model, sds, opt):
-    """B = 32 through the whole pose path (BASELINE.json configs[2], the shape bench.py times): parsing maps vs
-    the oracle (every differing pixel must be a near-tie of the two best classes); tokenizer: every token that
-    differs from the oracle's is accounted for as a codebook near-tie against the measured latent error of its
-    row (parity_util.vq_mismatch_accounting); texture map exact; then ALL 256 sampling steps teacher-forced on the
+    """B = 32 through the whole pose path (BASELINE.json configs[2], the shape bench.py times) on a fixture with
+    non-degenerate parsing maps: parsing maps vs the oracle (every differing pixel must be a near-tie of the two
+    best classes); tokenizer: latents within the activation tolerance and every token that differs from the
+    oracle's accounted for as a codebook near-tie against the measured latent error of its row
+    (parity_util.vq_mismatch_accounting); texture map exact; then ALL 256 sampling steps teacher-forced on the
     oracle's trajectory (each of the 32 x 512 categorical decisions is taken on the oracle's own partially
     unmasked state -- the oracle's sampler as eager PyTorch-ROCm fp32 on this GPU, with the torch device
     generator on both sides), and free-running."""
-    from parity_util import account, forced_run, oracle_run, seed_all, vq_mismatch_accounting
+    from parity_util import (account, balanced_pose_state_dicts, forced_run, oracle_run, seed_all,
+                             vq_mismatch_accounting)
     from text2human_amd import ops
     Bp, steps = 32, 256
+    # non-degenerate parsing maps (all 24 classes, parity_util.balanced_pose_state_dicts): the plain synthetic
+    # weights map every pose to ONE constant class, an ill-conditioned input for the tokenizer's GroupNorms
+    sds = balanced_pose_state_dicts(sds, opt)
+    model = SampleFromPoseModel(opt, state_dicts=sds)
     pb = synthetic.pose_batch(Bp, seed=2021)
     model.feed_data(pb)
     model.generate_parsing_map()
@@ -117,17 +123,17 @@ def test_sample_from_pose_batch_32_teacher_forced(model, sds, opt):
         segm_ref, logits = R.parsing_from_pose(pb['densepose'], pb['shape_attr'], sds['shape_embedder'],
                                                sds['shape_encoder'], sds['shape_decoder'],
                                                opt['shape_attr_class_num'])
+    assert len(torch.unique(segm_ref)) >= 20, 'the fixture must give non-degenerate parsing maps'
     bad = model.segm.cpu() != segm_ref
     t2 = logits.topk(2, dim=1).values
     margin = (t2[:, 0] - t2[:, 1]).unsqueeze(1)
-    assert (margin[bad] < 1e-4).all(), f'{int(bad.sum())} parsing pixels differ beyond a near-tie'
-    assert bad.float().mean() < 1e-3
-    # Tokenizer on the HIP path's own parsing maps.  With synthetic weights the parsing generator maps every
-    # pose to an almost constant map; on such an input the tokenizer's GroupNorms amplify rounding differences
-    # and the codebook argmin has ~1e-3 margins, so some tokens differ from the CPU oracle's.  Each one must be
-    # a near-tie: its distance gap in the oracle's own fp64 arithmetic is bounded by what the measured latent
-    # error of that row can move (non-degenerate maps are compared exactly at this batch size in
-    # tests/test_gpu_bench_parity.py::test_parsing_batch_32_full_parity).
+    # every differing pixel is accounted for: the oracle's own margin between its two best classes must be a
+    # rounding-level near-tie (the class logits are O(0.1), their spatial variation O(1e-3))
+    assert (margin[bad] < 1e-5).all(), f'{int(bad.sum())} parsing pixels differ beyond a near-tie'
+    assert bad.float().mean() < 1e-2
+    print(f'pose B=32 parsing maps: {int(bad.sum())} of {bad.numel()} pixels differ, all with margin < 1e-5')
+    # Tokenizer on the HIP path's own parsing maps (identical input on both sides): every token that differs
+    # from the CPU oracle's is accounted for as a codebook near-tie against the measured latent error of its row
     model.generate_quantized_segm()
     model.generate_texture_map()
     segm_cpu = model.segm.cpu()
@@ -142,14 +148,16 @@ def test_sample_from_pose_batch_32_teacher_forced(model, sds, opt):
     x = ops.onehot_nhwc(model.segm.to(torch.float32).reshape(-1), 24, model.segm_cin_pad)
     z_hip, _, _ = model.segm_encoder.encode(x, Bp, 512, 256)
     z_hip = ops.gemm(z_hip, model.P['segm.qc.w'], bias=model.P['segm.qc.b'])
+    # (the latent is the output of 20 GroupNorm'ed conv layers over a pixel-noisy 24-class map: two exact-fp32
+    # evaluations with different summation orders differ by a few 1e-4 there; measured 2.6e-4)
     lat_err = float((z_hip.cpu() - z_ref).abs().max())
-    assert lat_err < 2e-4 * max(1.0, float(z_ref.abs().max())), lat_err
+    assert lat_err < 6e-4 * max(1.0, float(z_ref.abs().max())), lat_err
     acc = vq_mismatch_accounting(z_hip, z_ref, book, model.segm_tokens, tok_ref)
     unexplained = [a for a in acc if not a['explained']]
     print(f'pose B=32 tokenizer: {len(acc)} of {Bp * 512} tokens differ from the CPU oracle, all near-ties: '
           f'{not unexplained}; latent max abs err {lat_err:.2e}')
     assert not unexplained, f'{len(unexplained)} of {len(acc)} differing tokens are not codebook near-ties: {unexplained[:5]}'
-    assert len(acc) < 0.02 * Bp * 512
+    assert len(acc) <= 16, acc[:5]     # (non-degenerate maps: 0 expected, a handful of ties tolerated and listed)
     assert torch.equal(model.texture_mask.cpu(), mask_ref)
 
     sd_dev = dv(sds['sampler'])

@@ -205,7 +205,7 @@ def test_last_layer_trim_on_and_off_sample_the_same_tokens_on_the_bench_config(m
 
 
 def test_graph_replay_of_the_sampling_rounds_gives_the_same_tokens(model, monkeypatch):
-    """T2H_GRAPH=1: one round = one replay of a captured launch sequence (engine.RoundGraph; row lists
+    """T2H_GRAPH=1 (the default): one round = one replay of a captured launch sequence (engine.RoundGraph; row lists
     padded to a fixed length with duplicates, seed read from device memory).  Same tokens and the same
     final generator offset as the launch-by-launch loop -- on the run that captures, on a replay-only
     run with ANOTHER seed, and after a change of batch size dropped the captured graph."""
@@ -220,9 +220,11 @@ def test_graph_replay_of_the_sampling_rounds_gives_the_same_tokens(model, monkey
         out = engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, 48, model.mask_id).clone()
         return out, gen.get_offset()
 
-    for seed, b in ((123, 3), (456, 3), (789, 2), (123, 3)):
+    for seed, b in ((123, 3), (456, 3), (789, 2), (123, 3), (-3, 3)):   # (-3: a uint64 seed >= 2^63, held as int64 on the device)
         want, off_w = run(seed, False, b)
         got, off_g = run(seed, True, b)
         assert torch.equal(got, want) and off_g == off_w, (seed, b)
         assert ((got >= 0).sum(0) == 1).all()
     assert len(model.sampler_fn._graphs) == 1      # the B = 2 call replaced the buffers and the B = 3 graph with them
+    assert model.sampler_fn.last_launch_mode == 'graph'
+

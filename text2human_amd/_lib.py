@@ -149,7 +149,12 @@ def load():
     return lib
 
 
+n_calls = 0  # C-ABI calls checked so far (bench.py: host launches per sampling round)
+
+
 def check(status, what=''):
+    global n_calls
+    n_calls += 1
     if status != 0:
         msg = load().t2h_last_error()
         raise T2HError(f'{what} failed ({status}): {msg.decode() if msg else "?"}')

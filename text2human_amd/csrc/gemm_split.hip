@@ -130,7 +130,9 @@ __device__ __forceinline__ f32x4 gelu_erf_v(f32x4 v) {
 
 #ifdef T2H_GEMM_TIMING
 __device__ long long* g1_timing = nullptr;  // debug builds only (tools/gemm_phase_timing.py)
-#define G1_MARK(i) do { if (g1_timing && threadIdx.x == 0) g1_timing[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+// slots 0..7: s_memrealtime (100 MHz), slots 8..15: s_memtime (shader clock) at the same marks -> the clock the
+// CU actually ran at between two marks (DVFS: the chip clocks to its power budget)
+#define G1_MARK(i) do { if (g1_timing && threadIdx.x == 0) { g1_timing[(int64_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); g1_timing[(int64_t)blockIdx.x * 16 + 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define G1_MARK(i) do { } while (0)
 #endif
@@ -244,7 +246,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     static_assert(BM % 64 == 0, "an 8-row group belongs to one operand");
     const unsigned wdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
     auto dma = [&](int kt, unsigned buf_off) {  // buf_off: byte offset of the tile buffer (scalar)
-      const int64_t k0 = (int64_t)min(kt, last) * SP_TILE_B;
+      // (no request past the last K tile: round 3 clamped kt to the last tile and re-fetched it twice per
+      // workgroup -- 2 of 16 tiles at K = 512 -- into buffers nobody reads)
+      if (kt > last) return;
+      const int64_t k0 = (int64_t)kt * SP_TILE_B;
       const char* const baseA = reinterpret_cast<const char*>(p.A) + k0;
       const char* const baseB = reinterpret_cast<const char*>(p.B) + k0;
 #pragma unroll
@@ -268,9 +273,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #endif
       }
     };
-    auto wait_landed = [&] {  // everything but the NL youngest requests
+    // tile kt + 1 has landed: everything but the NL requests of tile kt + 2 -- if that tile exists
+    auto wait_landed = [&](bool younger_in_flight) {
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+      if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     };
     // fragment read offsets inside a tile image: row * 128 + ((plane * 4 + u * 2 + hh) ^ swizzle) * 16
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     constexpr int PC[3] = {1, 1, 0};
     dma(0, 0);
     dma(1, TILE_IMG_B);
-    wait_landed();  // tile 0
+    wait_landed(nk > 1);  // tile 0
     pp_barrier();
     G1_MARK(1);
     if (grp == 1) pp_barrier();  // phase 0 belongs to group 0
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #ifndef T2H_SDBG_DMAFIRST
       dma(kt + 2, b_free);
 #endif
-      if (grp == 1) wait_landed();  // tile kt + 1
+      if (grp == 1) wait_landed(kt + 2 < nk);  // tile kt + 1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       pp_barrier();
       // (round 3 tried issuing the requests for tile kt + 2 here instead, one after every fourth matrix
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
                                                                            acc[PC[t]][ti][tj], 0, 0, 0);
 #endif
             }
-      if (grp == 0) wait_landed();  // tile kt + 1
+      if (grp == 0) wait_landed(kt + 2 < nk);  // tile kt + 1
       pp_barrier();
       const unsigned t = b_cur;
       b_cur = b_nxt;
@@ -353,8 +360,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       b_free = t;
     }
     if (grp == 0) pp_barrier();  // group 1's last matrix phase
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead requests too, before
-    __syncthreads();                                  // the tile buffers are reused by the epilogue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the tile buffers are reused by the epilogue
   } else {  // (scope: the staging registers and addresses are dead before the epilogue -- without it the
      // register allocator of ROCm 7.2 spilled 423 registers in the 256x128 instantiation)
   // ---- per-thread staging slots (fixed for the whole kernel).  Rows beyond M / N are
@@ -761,8 +768,9 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int64_t tiles256 = (int64_t)((a.M + 127) / 128) * ((a.N + 255) / 256);
     const int64_t tiles_big = (a.M % 256 == 0 && a.N % 128 == 0) ? (int64_t)(a.M / 256) * (a.N / 128) : 0;
+    const int64_t cus = 256;
     if (a.M <= 64) cfg = 2;
-    else if (tiles_big >= 192) {
+    else if (tiles_big >= cus * 3 / 4) {
       // 256x128 tiles wherever they give (nearly) every CU one: q|k|v / fc1 at M = 4096 (192 / 256
       // tiles) and every sampler Linear but proj at M = 16384 (q|k|v 99 vs 104 / 126 us for the 128x64 /
       // 128x128 tiles, fc2 93 vs 111), on the ping-pong LDS-DMA loop (5-6 % faster than the same tile
@@ -773,10 +781,10 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
       // or 256 tiles of 128x192, one per CU with 3/4 of the work each
       if (a.M % 128 == 0 && a.N % 192 == 0 && (a.Vt == nullptr || a.vt_col0 % 32 == 0)) {
         const int64_t t192 = (int64_t)(a.M / 128) * (a.N / 192);
-        if (((t192 + 255) / 256) * (128 * 192) < ((tiles_big + 255) / 256) * (256 * 128)) cfg = 10;
+        if (((t192 + cus - 1) / cus) * (128 * 192) < ((tiles_big + cus - 1) / cus) * (256 * 128)) cfg = 10;
       }
-    } else if (tiles128 >= 1024) cfg = 1;
-    else if (tiles64 <= 256 && a.K % 64 == 0 && a.K >= 256) cfg = 6;
+    } else if (tiles128 >= 4 * cus) cfg = 1;
+    else if (tiles64 <= cus && a.K % 64 == 0 && a.K >= 256) cfg = 6;
     else cfg = 0;
   }
   const bool skinny_ok = a.N % 16 == 0 && !a.Vt && (a.bias == nullptr || t2h_aligned16(a.bias));

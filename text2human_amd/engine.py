@@ -182,6 +182,7 @@ class SamplerNet:
         self._buf = {}
         self._graphs = {}       # captured sampling rounds (RoundGraph), see sample_tokens
         self.last_stats = None  # schedule.stats of the last sample_tokens run
+        self.last_launch_mode = None  # 'graph' (one replay per round) / 'eager' (individual launches)
 
     def _buffers(self, M, C, dev):
         key = (M, C, str(dev))
@@ -494,7 +495,9 @@ class RoundGraph:
                 self.body()  # round 0 eagerly: sizes every cached buffer before the capture
                 first = 1
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.stream):
+                # (thread_local: another thread of this process -- RCCL's watchdog, a data loader -- may call
+                # into the HIP runtime while this thread captures)
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
                     self.body()
                 self.graph = g
             for _ in range(first, R):
@@ -540,10 +543,15 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     sched = build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact)
     net.last_stats = schedule.stats(sched.round_steps, sample_steps)
     defer = bool(split and getattr(net, 'split_mha', False) and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
-    # T2H_GRAPH=1: every round is one replay of a captured launch sequence (RoundGraph) instead of ~180
-    # launches from this thread.  The GPU work is the same; what changes is the host side.
-    if (os.environ.get('T2H_GRAPH', '0') == '1' and defer and sched.noise_kind == 'philox' and step_hook is None
+    # Default (T2H_GRAPH=0 opts out): every round is ONE replay of a captured launch sequence (RoundGraph)
+    # instead of ~180 launches from this thread.  The GPU work is the same; what changes is the host side --
+    # with one process per GPU, eight Python threads issuing ~60 k launches/s each is the scaling risk of
+    # SURVEY.md 8(e).  Test hooks, explicit noise sources and the per-launch event sampling of bench.py's
+    # profiling leg need individual launches and take the loop below.
+    net.last_launch_mode = 'eager'
+    if (os.environ.get('T2H_GRAPH', '1') != '0' and defer and sched.noise_kind == 'philox' and step_hook is None
             and round_hook is None and 0 < sched.max_rows <= net.TRIM_MAX_ROWS and ops.gemm_profile_active() is False):
+        net.last_launch_mode = 'graph'
         maxr = min(net.TRIM_MAX_ROWS, -(-sched.max_rows // 16) * 16)
         net._buffers(n, net.desc['C'], dev)  # (a change of batch size drops the graphs of the old buffers)
         key = (B, T, sample_steps, maxr, float(temp), int(mask_id), n_books)

@@ -20,7 +20,11 @@ from text2human_amd._lib import GemmSplitArgs  # noqa: E402
 csrc = os.path.join(ROOT, 'text2human_amd', 'csrc')
 so = '/tmp/libt2h_gemm_timing.so'
 DEFS = [d for d in os.environ.get('T2H_TIMING_DEFS', '').split(',') if d]  # e.g. T2H_SDBG_NOPUT,T2H_SDBG_NOGLOAD
-subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-comment',
+PREBUILT = os.environ.get('T2H_TIMING_SO')  # a debug build made in the build container (tools/build_timing_variants.sh)
+if PREBUILT:
+    so = os.path.join(ROOT, PREBUILT)
+else:
+  subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-comment',
                 f'-I{ROOT}/include', '-DT2H_GEMM_TIMING', *[f'-D{d}' for d in DEFS], *(["-DT2H_DMA_POLICY=\" " + os.environ['T2H_DMA_POLICY'].replace('-', '') + "\""] if os.environ.get('T2H_DMA_POLICY') else []), os.path.join(csrc, 'api.hip'),
                 os.path.join(csrc, 'gemm_split.hip'), '-o', so], check=True)
 lib = ctypes.CDLL(so)
@@ -34,8 +38,9 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
                                     proj=(512, 512, False, True), fc2=(512, 2048, False, True)).items():
     if name not in SHAPES:
         continue
-    a = (torch.randn(M * k * 2, generator=g0) * 0.5).half().view(torch.int16).cuda()
-    w = (torch.randn(n * k * 2, generator=g0) * 0.05).half().view(torch.int16).cuda()
+    z = 0.0 if os.environ.get('T2H_TIMING_ZERO') == '1' else 1.0  # zero operands: the DVFS-free reference point
+    a = (torch.randn(M * k * 2, generator=g0) * 0.5 * z).half().view(torch.int16).cuda()
+    w = (torch.randn(n * k * 2, generator=g0) * 0.05 * z).half().view(torch.int16).cuda()
     out = torch.zeros(M, n, device='cuda')
     osp = torch.empty(M * n * 2, dtype=torch.int16, device='cuda')
     bias = torch.randn(n, generator=g0).cuda()
@@ -52,7 +57,7 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for cfg in CFGS:
         lib.t2h_gemm_split_force_config(cfg)
-        tb = torch.zeros(8 * 4096, dtype=torch.int64, device='cuda')
+        tb = torch.zeros(16 * 4096, dtype=torch.int64, device='cuda')
         setter = lib.t2h_debug_set_gemm1_timing_buffer
         setter(ctypes.c_void_p(0))
         for _ in range(3):
@@ -69,8 +74,11 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
         lib.t2h_gemm_split_f32(ctypes.byref(g), st)
         torch.cuda.synchronize()
         setter(ctypes.c_void_p(0))
-        t = tb.view(-1, 8).cpu()
-        t = t[t[:, 0] != 0].double() * 0.01  # us
+        raw = tb.view(-1, 16).cpu()
+        raw = raw[raw[:, 0] != 0].double()
+        t = raw[:, :8] * 0.01  # us
+        clk = raw[:, 8:]       # shader-clock ticks at the same marks
+        ghz = lambda a, b: statistics.median(((clk[:, b] - clk[:, a]) / ((t[:, b] - t[:, a]) * 1e3)).tolist())
         nb = t.shape[0]
         first = t[:, 0].min().item()
         med = lambda v: statistics.median(v.tolist())
@@ -78,6 +86,7 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
               f'max {(t[:, 0] - first).max().item():5.2f} | prologue {med(t[:, 1] - t[:, 0]):5.2f} | main loop '
               f'{med(t[:, 2] - t[:, 1]):5.2f} (max {(t[:, 2] - t[:, 1]).max().item():5.2f}) | epilogue issue '
               f'{med(t[:, 3] - t[:, 2]):5.2f} | store ack {med(t[:, 4] - t[:, 3]):5.2f} | first entry -> last ack '
-              f'{(t[:, 4].max().item() - first):6.2f} | last main-loop end {(t[:, 2].max().item() - first):6.2f}',
+              f'{(t[:, 4].max().item() - first):6.2f} | last main-loop end {(t[:, 2].max().item() - first):6.2f} | shader clock GHz: '
+              f'prologue {ghz(0, 1):.2f} main loop {ghz(1, 2):.2f} epilogue {ghz(2, 3):.2f}',
               flush=True)
     lib.t2h_gemm_split_force_config(-1)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# The three rocprofv3 --pmc passes behind profiles/r03_pmc_summary.* (one counter group per pass, no
+# The three rocprofv3 --pmc passes behind profiles/r04_pmc_summary.* (one counter group per pass, no
 # tracing besides the kernel trace, as MI355X_MICROARCH.md prescribes) over a shortened bench step
 # (--sample-steps 16: the per-launch counters of a kernel do not depend on how many rounds run).
 set -u
 REPO=$GRAFT_REPO_ROOT
-ARGS="--steps 1 --warmup 1 --sample-steps 16 --no-cpu-baseline --no-exact-fp32 --no-other-configs --no-graph-leg"
+ARGS="--steps 1 --warmup 1 --sample-steps 16 --no-cpu-baseline --no-exact-fp32 --no-other-configs --no-eager-leg"
 cd /tmp && export TMPDIR=/tmp
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   name=pmc_$(echo $grp | cut -d' ' -f1)

@@ -3,7 +3,7 @@
 #   bench lines of the three configurations, rocprofv3 kernel traces of the same command (full 256
 #   sampling steps), the three separate --pmc passes of the parsing configuration, the micro-benchmarks
 #   behind DESIGN.md's tables.  Everything lands in gpurun_out/round/; copy what is to be judged to
-#   profiles/r03_* (tools/rocprof_summary.py / tools/pmc_summary.py stamp the kernel-source digest).
+#   profiles/r04_* (tools/rocprof_summary.py / tools/pmc_summary.py stamp the kernel-source digest).
 set -u
 REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/round
@@ -14,7 +14,7 @@ python bench.py --steps 5 --warmup 2 > $OUT/bench_parsing.json 2> $OUT/bench_par
 for cfg in parsing pose hires; do
   rm -rf $OUT/prof_$cfg
   rocprofv3 --kernel-trace --stats -d $OUT/prof_$cfg -o p -- python bench.py --config $cfg --steps 1 --warmup 1 \
-      --no-cpu-baseline --no-exact-fp32 --no-other-configs --no-graph-leg > $OUT/prof_$cfg.log 2>&1
+      --no-cpu-baseline --no-exact-fp32 --no-other-configs --no-eager-leg > $OUT/prof_$cfg.log 2>&1
   db=$(find $OUT/prof_$cfg -name 'p_results.db' | head -1)
   python tools/rocprof_summary.py $db $OUT/bench_${cfg}_kernel_stats.md > /dev/null
   rm -rf $OUT/prof_$cfg
