@@ -50,6 +50,7 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16 / bf16 MFMA dense (NOT the 2:1-sparse figure)
 HBM_PEAK_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec
+MAX_CLOCK_GHZ = 2.4             # MI355X_MICROARCH.md: max clock, the clock the MFMA peaks are quoted at
 
 # algorithmic work per image (exact, 2 * MAC) and algorithmic HBM bytes
 GFLOP_IMAGE = dict(sampler_step=99.858, tokenizer=40.49, refine=2.19, decode=562.88, pose=239.86,
@@ -158,12 +159,34 @@ def cpu_baseline(sample_steps, n_sub, repeats):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         if line:
-            return json.loads(line[-1])
+            out = json.loads(line[-1])
+            out['calibration'] = reference_calibration()
+            return out
         return dict(value=None, unit='images/s', cores=threads, kind='port',
                     sample=f'worker failed: {r.stderr[-300:]}')
     except subprocess.TimeoutExpired:
         return dict(value=None, unit='images/s', cores=threads, kind='port',
                     sample='worker exceeded its 300 s time box')
+
+
+def reference_calibration():
+    """How the port (oracle/torch_ref.py, what `cpu_baseline` times here) relates to the UNMODIFIED reference on the
+    same cores: the reference cannot travel to the GPU box, so oracle/time_reference_vs_port.py times both in the
+    build container (same synthetic checkpoints, parsing map and seed; tokens and image identical) and the committed
+    result is quoted here.  ratio < 1: the port is FASTER than the reference, i.e. the baseline is generous."""
+    path = os.path.join(ROOT, 'profiles', 'r04_cpu_reference_vs_port.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    ref, port = d['reference'], d['port']
+    return {'source': 'profiles/r04_cpu_reference_vs_port.json (oracle/time_reference_vs_port.py, build container)',
+            'sampler_steps': d['config']['sampler_steps'], 'threads': d['config']['threads'], 'batch': d['config']['batch'],
+            'port_over_reference_time': {'tokenizer': d['ratio_port_over_reference_tokenizer_s'],
+                                         'sampler': d['ratio_port_over_reference_sampler_s'],
+                                         'refine_decode': d['ratio_port_over_reference_refine_decode_s']},
+            'reference_s': {k: ref[k] for k in ('tokenizer_s', 'sampler_s', 'refine_decode_s')},
+            'port_s': {k: port[k] for k in ('tokenizer_s', 'sampler_s', 'refine_decode_s')},
+            'tokens_equal': d['tokens_equal'], 'image_max_abs': d['image_max_abs']}
 
 
 def eager_gpu_baseline(model, batch, sds, n_sub, dev):
@@ -211,14 +234,14 @@ def profile_side_data(kernel_label, config):
     dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate
     passes of this same bench command, gfx950 FETCH x2 correction, tools/pmc_summary.py) and its
     average duration by rocprofv3 --kernel-trace (tools/rocprof_summary.py) -- launch-weighted over
-    the kernel's shapes.  Read from the committed round-3 summaries, and ONLY if they were taken
+    the kernel's shapes.  Read from the committed round-4 summaries, and ONLY if they were taken
     from this tree's kernel sources (digest check); otherwise the fields are null."""
     out = {'traffic': None}
     if not kernel_label.startswith('gemm_split'):
         return out
     want = kernel_src_digest()
     tag = '' if config == 'parsing' else f'_{config}'
-    path = os.path.join(ROOT, 'profiles', f'r03_pmc_summary{tag}.json')
+    path = os.path.join(ROOT, 'profiles', f'r04_pmc_summary{tag}.json')
     if os.path.exists(path):
         d = json.load(open(path))
         if d.get('kernel_src_sha') == want:
@@ -232,7 +255,7 @@ def profile_side_data(kernel_label, config):
                                           f'kernel sources {want})')
         else:
             out['traffic_note'] = f'profiles/{os.path.basename(path)} is from other kernel sources ({d.get("kernel_src_sha")} != {want})'
-    path = os.path.join(ROOT, 'profiles', f'r03_bench_{config}_kernel_stats.json')
+    path = os.path.join(ROOT, 'profiles', f'r04_bench_{config}_kernel_stats.json')
     if os.path.exists(path):
         d = json.load(open(path))
         if d.get('kernel_src_sha') == want:
@@ -252,6 +275,10 @@ def init_dist(backend, dev):
     the ONE JSON line, so fd 1 is routed to stderr while the communicator comes up."""
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if int(os.environ.get('WORLD_SIZE', 1)) == 1:  # T2H_FORCE_DIST=1 without a launcher: a one-rank group
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('MASTER_PORT', '29531')
     sys.stdout.flush()
     saved_fd = os.dup(1)
     os.dup2(2, 1)
@@ -299,9 +326,36 @@ class StubModel:
         self.segm = batch['segm']
         self.batch_size = self.segm.shape[0]
 
+    last_stats = None
+    last_launch_mode = 'graph'
+
     def sample_fn(self, temp=1, sample_steps=None):
+        """Walks the HOST logic of the product's graph-replay sampler (schedule.group_rounds -> schedule.RoundTables
+        -> one "replay" per round, engine.RoundGraph.run) on this rank's shard with a schedule drawn from the
+        (re-seeded) global generator: every token row must be sampled exactly once, in a round of its own sample."""
+        import numpy as np
+        from text2human_amd import schedule
         time.sleep(0.01)
-        r = torch.rand(self.batch_size, 4)  # consumes the (re-seeded) global generator
+        B, T, steps = self.batch_size, 16, 12
+        u = torch.rand(steps, B * T).numpy()  # consumes the global generator like the reference's per-step rand
+        step = np.zeros(B * T, dtype=np.int64)
+        for i, t in enumerate(range(steps, 0, -1)):
+            hit = (u[i] < 1.0 / t) & (step == 0)
+            step[hit] = t
+        order, start, round_steps = schedule.group_rounds(step, B, T, compact=True)
+        maxr = -(-int(np.diff(start).max()) // 16) * 16
+        tables = schedule.RoundTables(order, order.astype(np.int64) * 3 + 1, start, maxr)
+        tok = np.full(B * T, -1, dtype=np.int64)
+
+        def body(rows, vals):
+            assert (vals == rows.astype(np.int64) * 3 + 1).all()
+            tok[rows] = rows % 7          # (padding repeats a row of the same round: the same token twice)
+
+        replays = tables.replay(body)
+        assert replays == tables.n_rounds - 1 and (tok >= 0).all()
+        StubModel.last_stats = dict(schedule.stats(round_steps, steps), replays=replays)
+        self.sampler_fn = self  # (ConfigRun.timed reads sampler_fn.last_stats / last_launch_mode)
+        r = torch.from_numpy(tok.reshape(B, T)[:, :4].astype(np.float64)) / 7.0
         return [(self.segm.reshape(self.batch_size, -1)[:, :4] + r + self.w).double()]
 
     def decode_indices(self, top, want_u8=True, upscale=False, return_inter=False):
@@ -346,6 +400,31 @@ def gemm_roofline(prof, config):
         'all_gemm_kernels': {k: {'TFLOP/s': v['flops'] / (v['ms'] * 1e-3) / 1e12, 'n': v['n'],
                                  'avg_us': 1000.0 * v['ms'] / v['n']} for k, v in prof.items()},
     }
+    if dom.get('n_probe'):
+        # phase stamps of the sampled launches (t2h_gemm_split_probe_next_launch): the clock the CUs really ran at
+        ghz = dom['loop_ghz'] / dom['n_probe']
+        r.update(main_loop_us=dom['loop_us'] / dom['n_probe'], main_loop_shader_clock_ghz=ghz,
+                 peak_at_measured_clock=peak * ghz / MAX_CLOCK_GHZ, frac_of_peak_at_measured_clock=ach / (peak * ghz / MAX_CLOCK_GHZ),
+                 clock_note=('s_memtime / s_memrealtime stamps around the main loop of the sampled launches, median over the '
+                             'workgroups: the chip clocks to its power budget, and with the matrix pipes and the LDS-DMA stream '
+                             f'both busy the CUs do not hold {MAX_CLOCK_GHZ} GHz (the {peak:.0f} TFLOP/s peak assumes they do); '
+                             'profiles/r04_gemm_one_wave_per_simd_and_clock.log'))
+    if split and dom.get('by_cfg'):
+        # one entry per tile configuration of the dispatcher (= template instantiation of gemm_split_kernel)
+        inst = {}
+        for k, v in dom['by_cfg'].items():
+            if not v['n']:
+                continue
+            e = {'n': v['n'], 'avg_us': 1000.0 * v['ms'] / v['n'], 'executed_TFLOP/s': mult * v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                 'frac': mult * v['flops'] / (v['ms'] * 1e-3) / 1e12 / peak}
+            if v['n_stream']:
+                e['avg_stream_interval_us'] = 1000.0 * v['ms_stream'] / v['n_stream']
+            if v['n_probe']:
+                g = v['loop_ghz'] / v['n_probe']
+                e.update(main_loop_us=v['loop_us'] / v['n_probe'], main_loop_shader_clock_ghz=g,
+                         frac_of_peak_at_measured_clock=e['frac'] * MAX_CLOCK_GHZ / g)
+            inst[k] = e
+        r['all_gemm_kernels'].update(inst)
     r.update(profile_side_data(dom['kernel'], config))
     if r.get('avg_launch_us_rocprof'):
         r['frac_rocprof_kernel_time'] = r['frac'] * r['avg_launch_us'] / r['avg_launch_us_rocprof']

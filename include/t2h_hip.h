@@ -167,6 +167,14 @@ int t2h_split_overflow_async(int32_t* flag, int32_t* host_out, int32_t reset, vo
  * start / end into the two hipEvent_t (hipExtLaunchKernelGGL: the kernel's timestamps, what rocprofv3's
  * kernel trace reports), then the hook disarms.  NULL, NULL disarms. */
 int t2h_gemm_split_time_next_launch(void* start_event, void* stop_event);
+/* measurement hook (tools/gemm_phase_timing.py, bench.py): the NEXT t2h_gemm_split_f32 launch of the calling thread
+ * stores phase stamps into dev_int64_buf[workgroups][16] (int64; the caller zeroes it and sizes it for the launch's
+ * grid, 4096 workgroups always suffice at the sampler's shapes): per workgroup s_memrealtime (100 MHz) in slots 0..3 and
+ * s_memtime (shader clock) in slots 8..11 at entry / prologue done / main loop done / epilogue stores issued -- phase
+ * lengths and the clock the CU really ran at in each phase.  Disarms after the launch; NULL disarms. */
+int t2h_gemm_split_probe_next_launch(void* dev_int64_buf);
+/* id of the tile configuration the dispatcher picks for `args` (profiling labels; ids as t2h_gemm_split_force_config) */
+int t2h_gemm_split_tile_config(const t2h_gemm_split_args* args);
 int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..3, 5, 6, 8 / 10 (ping-pong LDS-DMA, 256x128 / 128x192), 9 (few-rows kernel), -1 auto;
                                               thread-local: it affects launches of the calling thread only */
 /* fp32 [rows, C] (row stride ldx) -> split rows */

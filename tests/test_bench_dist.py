@@ -48,6 +48,8 @@ def test_bench_two_ranks_gloo():
     # the configs[3] leg ran on both ranks too (its barrier / max-over-ranks collectives are the headline's)
     leg = out['other_configs']['parsing_b32']
     assert leg['config']['global_batch'] == 2 * 2 * 3 and leg['value'] > 0 and leg['steps'] == 2
+    # the stub walks the graph-replay host logic (schedule.RoundTables) on every rank's own shard
+    assert leg['launch_mode'] == 'graph' and leg['stages'] == {}
     # the shards are those of the single-process run over the same global batch
     one = _run(1, ('--batch', '6'))
     assert one['rccl_world'] == 1 and len(one['per_rank_image_checksum']) == 1

@@ -228,3 +228,55 @@ def test_graph_replay_of_the_sampling_rounds_gives_the_same_tokens(model, monkey
     assert len(model.sampler_fn._graphs) == 1      # the B = 2 call replaced the buffers and the B = 3 graph with them
     assert model.sampler_fn.last_launch_mode == 'graph'
 
+
+
+def test_graph_capture_and_replay_beside_a_live_rccl_communicator(opt, sds, monkeypatch):
+    """The product default (one captured hipGraph per sampling round) next to a live RCCL communicator, as every
+    rank of a multi-GPU run has it (bench.py / shard.py: weights broadcast, barriers, gathers): a one-rank NCCL
+    process group is created in this process, a collective runs on it, and a FRESH model then captures its round
+    graph and replays it, with another collective between two runs.  Tokens must equal the launch-by-launch loop's."""
+    import socket
+    import torch.distributed as dist
+    from text2human_amd import engine
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        t = torch.ones(1024, device=DEV)
+        dist.all_reduce(t)                 # the communicator really exists
+        dist.barrier()
+        model = SampleFromParsingModel(opt, state_dicts=sds)
+        model.feed_data(synthetic.parsing_batch(3, seed=41))
+        tex_tok = model._texture_tokens(model.texture_mask)
+
+        def run(seed, graph):
+            monkeypatch.setenv('T2H_GRAPH', '1' if graph else '0')
+            torch.cuda.manual_seed_all(seed)
+            return engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, 40, model.mask_id).clone()
+
+        for seed in (5, 6):
+            got = run(seed, True)          # seed 5 captures, seed 6 only replays
+            assert model.sampler_fn.last_launch_mode == 'graph'
+            dist.all_reduce(t)             # a collective between the graph runs
+            assert torch.equal(got, run(seed, False)), seed
+        torch.cuda.synchronize()
+        assert float(t[0]) == 1.0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_decoder_attention_flash_fallback_matches_the_materialised_default(model, monkeypatch):
+    """The decoders' AttnBlocks run the materialised bmm -> softmax -> bmm form unless the N x N score tensor exceeds
+    T2H_ATTN_SCORE_MB; with the budget at 0 every one of them takes the flash-style kernel instead.  Same image."""
+    top, mask = _rand_indices(2, seed=77)
+    model.texture_mask, model.batch_size = mask.to(DEV), 2
+    img_a, _ = model.decode_indices([t.to(DEV) for t in top])
+    monkeypatch.setenv('T2H_ATTN_SCORE_MB', '0')
+    img_b, _ = model.decode_indices([t.to(DEV) for t in top])
+    assert (img_a - img_b).abs().max().item() < 2e-4
+    assert not torch.equal(img_a, img_b)     # (another kernel really ran)

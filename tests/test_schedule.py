@@ -96,3 +96,27 @@ def test_seed_as_int64_roundtrip():
         assert -2**63 <= i < 2**63 and (i & 0xFFFFFFFFFFFFFFFF) == u
         t = torch.empty(1, dtype=torch.int64).fill_(i)      # (fill_(u) itself raises for u >= 2^63)
         assert int(t.view(torch.uint8).numpy().view('<u8')[0]) == u
+
+
+def test_round_tables_replay_visits_every_row_in_its_own_round():
+    """schedule.RoundTables = the host bookkeeping of graph replay with the CPU statement of t2h_schedule_advance."""
+    B, T, steps = 5, 64, 30
+    step = _random_schedule(B, T, steps, seed=21)
+    order, start, round_steps = schedule.group_rounds(step, B, T, compact=True)
+    offs = (order * 11 + 5).astype(np.int64)
+    maxr = -(-int(np.diff(start).max()) // 16) * 16
+    tb = schedule.RoundTables(order, offs, start, maxr)
+    seen, rounds = np.zeros(B * T, dtype=np.int64), []
+
+    def body(rows, vals):
+        r = len(rounds)
+        rounds.append(rows)
+        assert rows.shape == (maxr, ) and (vals == rows.astype(np.int64) * 11 + 5).all()
+        uniq = np.unique(rows)
+        assert (step[uniq] == round_steps[r, uniq // T]).all()     # every listed row belongs to THIS round
+        seen[uniq] += 1
+
+    assert tb.replay(body) == tb.n_rounds - 1 == len(rounds) - 1
+    assert (seen == 1).all()
+    with pytest.raises(IndexError):
+        tb.advance()

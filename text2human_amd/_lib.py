@@ -66,6 +66,8 @@ SIGNATURES = {
     't2h_gemm_split_f32': (ctypes.c_int, [ctypes.POINTER(GemmSplitArgs), c_vp]),
     't2h_gemm_split_time_next_launch': (ctypes.c_int, [c_vp, c_vp]),
     't2h_gemm_split_force_config': (ctypes.c_int, [ctypes.c_int]),
+    't2h_gemm_split_probe_next_launch': (ctypes.c_int, [c_vp]),
+    't2h_gemm_split_tile_config': (ctypes.c_int, [ctypes.POINTER(GemmSplitArgs)]),
     't2h_conv3x3_small_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32,
                                              c_i32, c_i32, c_vp]),
     't2h_conv_split_force_tile': (ctypes.c_int, [ctypes.c_int]),

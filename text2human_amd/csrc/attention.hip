@@ -284,6 +284,9 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform values in scalar registers
   const long long tm0 = TM_NOW();
+#ifdef T2H_MHA_TIMING
+  const long long rt0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   long long tm_stage = 0, tm_comp = 0;
   if (tid < 2) bar[tid] = 0;
   __syncthreads();
@@ -394,6 +397,9 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
 
   int bar_n = 0;
   const long long tm1 = TM_NOW();
+#ifdef T2H_MHA_TIMING
+  const long long rt1 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   // the second-dispatched half of the workgroup loses every issue arbitration against its older SIMD
   // partner (measured: its loop took 37k cycles against 26k): static priority evens the two out
   if (kh == 1) __builtin_amdgcn_s_setprio(1);
@@ -508,6 +514,9 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
     for (int r = 0; r < 16; ++r) o_acc[dt][r] = fmaf(o_lo[dt][r], T2H_SPLIT_LO_INV, o_acc[dt][r]);
   // ---- merge the two key halves: waves 4-7 publish (m, l, O), waves 0-3 combine
   const long long tm2 = TM_NOW();
+#ifdef T2H_MHA_TIMING
+  const long long rt2 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   __syncthreads();
   float* const Ox = smem;                // [4 waves][32 regs][64 lanes]
   float* const Mx = smem + 4 * 32 * 64;  // borrowed from the staging area below:
@@ -565,6 +574,9 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
     long long* o = g_mha_timing + (wave == 4 ? 8 : 0);
     const long long te = clock64();
     o[0] = te - tm0; o[1] = tm1 - tm0; o[2] = tm_stage; o[3] = tm_comp; o[4] = te - tm2; o[5] = tm2 - tm1;
+    // s_memrealtime (100 MHz) spans of the same phases: total, prologue, loop -> the clock of each
+    const long long rte = (long long)__builtin_amdgcn_s_memrealtime();
+    o[6] = rte - rt0; o[7] = (rt1 - rt0) | ((rt2 - rt1) << 32);
   }
 #endif
 }

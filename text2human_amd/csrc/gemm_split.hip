@@ -128,14 +128,19 @@ __device__ __forceinline__ f32x4 gelu_erf_v(f32x4 v) {
 #define LN0 n0
 #endif
 
-#ifdef T2H_GEMM_TIMING
-__device__ long long* g1_timing = nullptr;  // debug builds only (tools/gemm_phase_timing.py)
-// slots 0..7: s_memrealtime (100 MHz), slots 8..15: s_memtime (shader clock) at the same marks -> the clock the
-// CU actually ran at between two marks (DVFS: the chip clocks to its power budget)
-#define G1_MARK(i) do { if (g1_timing && threadIdx.x == 0) { g1_timing[(int64_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); g1_timing[(int64_t)blockIdx.x * 16 + 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } } while (0)
-#else
-#define G1_MARK(i) do { } while (0)
-#endif
+// Phase stamps (t2h_gemm_split_probe_next_launch; tools/gemm_phase_timing.py, bench.py): when the launch carries a
+// probe buffer [workgroups][16] int64, thread 0 of every workgroup stores s_memrealtime (100 MHz, slots 0..7) and
+// s_memtime (shader clock, slots 8..15) at entry (0), prologue done (1), main loop done (2), epilogue stores issued
+// (3) -> phase lengths AND the clock the CU actually ran at in each phase (DVFS: the chip clocks to its power
+// budget; the main loop of the B = 8 shapes runs at ~1.5 GHz, not 2.4).  probe == nullptr (every product launch):
+// one scalar compare per mark.
+#define G1_MARK(i)                                                                                      \
+  do {                                                                                                  \
+    if (probe != nullptr && threadIdx.x == 0) {                                                         \
+      probe[(int64_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime();              \
+      probe[(int64_t)blockIdx.x * 16 + 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();              \
+    }                                                                                                   \
+  } while (0)
 
 // KS = 2: in-block K split.  Two wave groups of WARPS_M x WARPS_N waves each own the
 // whole BM x BN tile, their own pair of LDS tile buffers and every second K tile (group
@@ -152,7 +157,7 @@ __device__ long long* g1_timing = nullptr;  // debug builds only (tools/gemm_pha
 // schedule with register staging, PP = 1 of round 2, gained nothing and was removed:
 // profiles/r02_gemm_pingpong_ablation_v*.log.)
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int PP>
-__global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p, int* const ovf) {
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p, int* const ovf, long long* const probe) {
   constexpr int NT = 64 * WARPS_M * WARPS_N;  // threads per K group
   constexpr int NWG = WARPS_M * WARPS_N;      // waves per K group
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -615,8 +620,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     }
     if (p.C_split) t2h_store_split8(p.C_split, row, p.N, col, va, vb, ovf);
   }
-#ifdef T2H_GEMM_TIMING
   G1_MARK(3);
+#ifdef T2H_GEMM_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G1_MARK(4);
 #endif
@@ -685,6 +690,7 @@ __global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t
 // trace reports) -- events recorded around a launch on the stream measure from the end of the
 // PREVIOUS kernel and so include the dependent-launch boundary
 thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+thread_local long long* g_probe = nullptr;  // t2h_gemm_split_probe_next_launch
 
 template <typename K, typename... Args>
 void launch_maybe_timed(K kernel, dim3 grid, dim3 block, hipStream_t s, Args... args) {
@@ -707,7 +713,7 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
   int* ovf = a.overflow_flag;
   launch_maybe_timed(gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP>, grid, dim3(64 * WARPS_M * WARPS_N * KS), s, a,
-                     ovf);
+                     ovf, g_probe);
   T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
   return T2H_OK;
 }
@@ -716,11 +722,10 @@ thread_local int g_force_split_cfg = -1;  // tuning / test hook of the calling t
 
 }  // namespace
 
-#ifdef T2H_GEMM_TIMING
-extern "C" int t2h_debug_set_gemm1_timing_buffer(void* dev_ptr) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g1_timing), &dev_ptr, sizeof(void*));
+extern "C" int t2h_gemm_split_probe_next_launch(void* dev_int64_buf) {
+  g_probe = static_cast<long long*>(dev_int64_buf);
+  return T2H_OK;
 }
-#endif
 
 extern "C" int t2h_gemm_split_time_next_launch(void* start_event, void* stop_event) {
   g_time_start = static_cast<hipEvent_t>(start_event);
@@ -734,30 +739,8 @@ extern "C" int t2h_gemm_split_force_config(int cfg) {
   return old;
 }
 
-extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream) {
-  // the timing hook is for THIS call: a call that fails a check before it launches must not leave the events
-  // armed for a later, unrelated launch
-  struct Disarm {
-    ~Disarm() { g_time_start = g_time_stop = nullptr; }
-  } disarm_on_exit;
-  T2H_REQUIRE(args != nullptr, "t2h_gemm_split_f32: args is NULL");
-  const t2h_gemm_split_args a = *args;
-  T2H_REQUIRE(a.A && a.B && (a.C || a.C_split || a.Vt), "t2h_gemm_split_f32: NULL operand");
-  T2H_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0, "t2h_gemm_split_f32: bad shape M=%d N=%d K=%d",
-              a.M, a.N, a.K);
-  T2H_REQUIRE(t2h_aligned16(a.A) && t2h_aligned16(a.B), "t2h_gemm_split_f32: operands must be 16-byte aligned");
-  T2H_REQUIRE(a.N % 8 == 0 && (!a.C || (a.ldc % 4 == 0 && t2h_aligned16(a.C))) &&
-                  (!a.residual || (a.ldr % 4 == 0 && t2h_aligned16(a.residual))),
-              "t2h_gemm_split_f32: N must be a multiple of 8, ldc / ldr of 4, C / residual 16-byte aligned");
-  if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
-  T2H_REQUIRE(a.overflow_flag != nullptr || (!a.C_split && !a.Vt),
-              "t2h_gemm_split_f32: overflow_flag is NULL (needed with C_split / Vt outputs)");
-  if (a.Vt)
-    T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 128 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&
-                    a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,
-                "t2h_gemm_split_f32: bad Vt routing (col0=%d T=%d hd=%d M=%d N=%d)", a.vt_col0, a.vt_T, a.vt_hd,
-                a.M, a.N);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+// tile configuration of the dispatcher for a (validated) problem
+static int pick_split_cfg(const t2h_gemm_split_args& a) {
   int cfg = g_force_split_cfg;
   if (cfg < 0) {
     // measured on MI355X at M = 4096 (tools/gemm_split_bench.py, profiles/): the 4-wave
@@ -789,7 +772,44 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
   }
   const bool skinny_ok = a.N % 16 == 0 && !a.Vt && (a.bias == nullptr || t2h_aligned16(a.bias));
   if (g_force_split_cfg < 0 && a.M <= 64 && skinny_ok) cfg = 9;
+  return cfg;
+}
+
+extern "C" int t2h_gemm_split_tile_config(const t2h_gemm_split_args* args) {
+  T2H_REQUIRE(args != nullptr && args->M > 0 && args->N > 0 && args->K > 0, "t2h_gemm_split_tile_config: bad arguments");
+  return pick_split_cfg(*args);
+}
+
+extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream) {
+  // the timing hook is for THIS call: a call that fails a check before it launches must not leave the events
+  // armed for a later, unrelated launch
+  struct Disarm {
+    ~Disarm() {
+      g_time_start = g_time_stop = nullptr;
+      g_probe = nullptr;
+    }
+  } disarm_on_exit;
+  T2H_REQUIRE(args != nullptr, "t2h_gemm_split_f32: args is NULL");
+  const t2h_gemm_split_args a = *args;
+  T2H_REQUIRE(a.A && a.B && (a.C || a.C_split || a.Vt), "t2h_gemm_split_f32: NULL operand");
+  T2H_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0, "t2h_gemm_split_f32: bad shape M=%d N=%d K=%d",
+              a.M, a.N, a.K);
+  T2H_REQUIRE(t2h_aligned16(a.A) && t2h_aligned16(a.B), "t2h_gemm_split_f32: operands must be 16-byte aligned");
+  T2H_REQUIRE(a.N % 8 == 0 && (!a.C || (a.ldc % 4 == 0 && t2h_aligned16(a.C))) &&
+                  (!a.residual || (a.ldr % 4 == 0 && t2h_aligned16(a.residual))),
+              "t2h_gemm_split_f32: N must be a multiple of 8, ldc / ldr of 4, C / residual 16-byte aligned");
+  if (a.C_split) T2H_REQUIRE(a.N % 32 == 0, "t2h_gemm_split_f32: split output needs N %% 32 == 0");
+  T2H_REQUIRE(a.overflow_flag != nullptr || (!a.C_split && !a.Vt),
+              "t2h_gemm_split_f32: overflow_flag is NULL (needed with C_split / Vt outputs)");
+  if (a.Vt)
+    T2H_REQUIRE(a.vt_hd > 0 && a.vt_T > 0 && a.vt_T % 128 == 0 && a.M % a.vt_T == 0 && a.vt_col0 >= 0 &&
+                    a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,
+                "t2h_gemm_split_f32: bad Vt routing (col0=%d T=%d hd=%d M=%d N=%d)", a.vt_col0, a.vt_T, a.vt_hd,
+                a.M, a.N);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int cfg = pick_split_cfg(a);
   if (cfg == 9) {
+    const bool skinny_ok = a.N % 16 == 0 && !a.Vt && (a.bias == nullptr || t2h_aligned16(a.bias));
     T2H_REQUIRE(skinny_ok, "t2h_gemm_split_f32: the few-rows kernel needs N %% 16 == 0 and no Vt routing");
     int* ovf = a.overflow_flag;
     launch_maybe_timed(gemm_split_skinny_kernel, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), s, a, ovf);

@@ -7,7 +7,9 @@ time, models/sample_model.py:220; every op is per-sample so batching is exact)
 and keeps activations as NHWC pixel rows [B*H*W, C] / token rows [B*T, C] in
 HBM.  PyTorch only allocates tensors and provides the stream.
 """
+import gc
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -26,8 +28,9 @@ class VQGANStack:
     def __init__(self, P, name, desc):
         self.P, self.name, self.desc = P, name, desc
         self.use_split = True  # False: exact-fp32 convolutions even if split-row weights were packed (A/B, bench parity)
-        # the decoders' AttnBlocks (N = 512 .. 8192 positions) run flash-style; the encoders' (tokenizer: an argmin
-        # decision pinned to golden tokens) keep the materialised bmm -> softmax -> bmm form
+        # the decoders' AttnBlocks (N = 512 .. 8192 positions) MAY run flash-style when the N x N score tensor is too
+        # large to allocate (attnblock); the encoders' (tokenizer: an argmin decision pinned to golden tokens) always
+        # keep the materialised bmm -> softmax -> bmm form
         self.flash_attn = False
 
     def _ws(self, key, hw, mode='same'):
@@ -86,11 +89,15 @@ class VQGANStack:
         """AttnBlock.forward (vqgan_arch.py:636-661)."""
         c = x.shape[1]
         qkv = self._conv1x1(x, f'{pfx}.qkv', n, pro=self._gn(x, f'{pfx}.norm', n_img, n))
-        # flash-style (no N x N tensor) once the launch fills the chip (32 queries per workgroup, >= one
-        # workgroup per CU): N = 2048 at B = 8, N = 8192 at 1024x512.  Below that (the top decoder's N = 512:
-        # 8 MB of scores for 8 images) the materialised form is 2x faster and its tensor is small.
-        # profiles/r03_spatial_attention_bench.log
-        if self.flash_attn and ops.spatial_attention_ok(n, c) and n_img * (n // 32) >= 256:
+        # The materialised form (bmm -> softmax -> bmm) is the default: it is FASTER than the flash-style kernel at
+        # every decoder shape (671 vs 845 us at N = 2048 / B = 8, 2501 vs 2981 us for two images at N = 8192,
+        # profiles/r03_spatial_attention_bench.log -- both run at 80-110 TF of the exact-fp32 rate and the score
+        # tensor's round trip is served by the Infinity Cache).  The flash-style kernel (no N x N tensor) takes over
+        # only where the score tensor would not be reasonable to allocate (T2H_ATTN_SCORE_MB, default 2048 MB:
+        # 268 MB per image at N = 8192).
+        score_mb = n_img * n * n * 4 / 2**20
+        if (self.flash_attn and ops.spatial_attention_ok(n, c)
+                and score_mb > float(os.environ.get('T2H_ATTN_SCORE_MB', '2048'))):
             return self._conv1x1(ops.spatial_attention(qkv, n_img, n, c), f'{pfx}.proj', n, residual=x)
         q3 = qkv.view(n_img, n, 3 * c)
         s = torch.empty((n_img, n, n), device=x.device, dtype=torch.float32)
@@ -453,7 +460,10 @@ class RoundGraph:
     def __init__(self, net, B, T, steps, maxr, n_books, n_class, temp, mask_id, dev):
         i64 = lambda *s: torch.empty(s, dtype=torch.int64, device=dev)
         i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
-        self.net, self.maxr, self.temp, self.mask_id = net, maxr, float(temp), mask_id
+        # (a weak reference: net._graphs owns this object -- a strong one would make a cycle that only the cyclic
+        # collector frees, at a moment of ITS choosing, e.g. in the middle of another graph's capture)
+        self._net = weakref.ref(net)
+        self.maxr, self.temp, self.mask_id = maxr, float(temp), mask_id
         self.x_t, self.out, self.segm, self.tex = i64(B, T), i64(n_books, B * T), i64(B, T), i64(B, T)
         self.rows_tbl, self.offs_tbl = i32(steps, maxr), i64(steps, maxr)
         self.cur_rows, self.cur_offs = i32(maxr), i64(maxr)
@@ -463,7 +473,8 @@ class RoundGraph:
         self.graph = None
 
     def body(self):
-        net, P, nm = self.net, self.net.P, self.net.name
+        net = self._net()
+        P, nm = net.P, net.name
         ops.schedule_advance(self.rows_tbl, self.offs_tbl, None, self.round_ctr, self.cur_rows, self.cur_offs, None,
                              self.maxr)
         net.hidden(self.x_t, self.segm, self.tex, defer_tail=True)
@@ -476,8 +487,8 @@ class RoundGraph:
         """All rounds of one run on this graph's stream; returns `out` (valid once the caller's stream
         has waited, which this does)."""
         order, offs = sched.host
-        R = sched.n_rounds
-        rows_tbl, offs_tbl = schedule.padded_tables(order, offs, sched.start, self.maxr)
+        tables = schedule.RoundTables(order, offs, sched.start, self.maxr)
+        R, rows_tbl, offs_tbl = tables.n_rounds, tables.rows_tbl, tables.val_tbl
         caller = torch.cuda.current_stream()
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
@@ -495,10 +506,17 @@ class RoundGraph:
                 self.body()  # round 0 eagerly: sizes every cached buffer before the capture
                 first = 1
                 g = torch.cuda.CUDAGraph()
-                # (thread_local: another thread of this process -- RCCL's watchdog, a data loader -- may call
-                # into the HIP runtime while this thread captures)
-                with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
-                    self.body()
+                # thread_local: another thread of this process -- RCCL's watchdog, a data loader -- may call into
+                # the HIP runtime while this thread captures.  No cyclic garbage collection inside the capture:
+                # a collected tensor / graph / event would be released through the runtime in the middle of it.
+                gc_was_on = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
+                        self.body()
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 self.graph = g
             for _ in range(first, R):
                 self.graph.replay()

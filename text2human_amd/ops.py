@@ -98,26 +98,62 @@ def gemm_profile_active():
     return _prof is not None
 
 
+SPLIT_CFG_NAMES = {0: '128x64', 1: '128x128', 2: '64x64', 3: '128x64, 8 waves', 5: '128x256', 6: '128x64, 2 K groups',
+                   8: '256x128, ping-pong LDS-DMA', 9: 'few rows (16x16 per workgroup, K over 8 waves)',
+                   10: '128x192, ping-pong LDS-DMA'}
+
+
+def _probe_clock(buf):
+    """(median main-loop time in us, median shader clock in GHz over the main loop) from a phase-stamp buffer of
+    t2h_gemm_split_probe_next_launch; None if the launch left no stamps (few-rows kernel)."""
+    t = buf.view(-1, 16).cpu()
+    t = t[(t[:, 1] != 0) & (t[:, 2] != 0)].double()
+    if t.shape[0] == 0:
+        return None
+    us = (t[:, 2] - t[:, 1]) * 0.01
+    ghz = (t[:, 10] - t[:, 9]) / (us * 1e3)
+    return float(us.median()), float(ghz.median())
+
+
 def gemm_profile_stop():
-    """-> {kernel label: dict(kernel, n, ms, flops)} (synchronises)."""
+    """-> {kernel label: dict(kernel, n, ms, flops, ...)} (synchronises).  The split GEMM appears once as
+    'gemm_split_kernel<2xfp16>' (all instantiations, launch-weighted) and once per tile configuration of the
+    dispatcher under that record's 'by_cfg'; records that carried a phase-stamp buffer add the main loop's
+    duration and the shader clock it ran at."""
     global _prof
     p, _prof = _prof, None
     if not p:
         return {}
     torch.cuda.synchronize()
     out = {}
-    for label, flops, e0, e1, *kind in p['recs']:
-        r = out.setdefault(label, dict(kernel=label, n=0, ms=0.0, flops=0.0, n_stream=0, ms_stream=0.0, flops_stream=0.0,
-                                       kernel_timed=False))
-        if kind and kind[0] == 'stream':  # interval on the stream: kernel + launch boundary
+
+    def add(r, flops, e0, e1, kind, probe):
+        if kind == 'stream':  # interval on the stream: kernel + launch boundary
             r['n_stream'] += 1
             r['ms_stream'] += e0.elapsed_time(e1)
             r['flops_stream'] += flops
-            continue
-        r['kernel_timed'] = r['kernel_timed'] or bool(kind)
+            return
+        r['kernel_timed'] = r['kernel_timed'] or kind == 'kernel'
         r['n'] += 1
         r['ms'] += e0.elapsed_time(e1)
         r['flops'] += flops
+        if probe is not None:
+            r['n_probe'] += 1
+            r['loop_us'] += probe[0]
+            r['loop_ghz'] += probe[1]
+
+    blank = lambda label: dict(kernel=label, n=0, ms=0.0, flops=0.0, n_stream=0, ms_stream=0.0, flops_stream=0.0,
+                               kernel_timed=False, n_probe=0, loop_us=0.0, loop_ghz=0.0)
+    for rec in p['recs']:
+        label, flops, e0, e1 = rec[:4]
+        kind = rec[4] if len(rec) > 4 else None
+        cfg = rec[5] if len(rec) > 5 else None
+        probe = _probe_clock(rec[6]) if len(rec) > 6 and rec[6] is not None else None
+        r = out.setdefault(label, blank(label))
+        add(r, flops, e0, e1, kind, probe)
+        if cfg is not None:
+            name = f'gemm_split_kernel<{SPLIT_CFG_NAMES.get(cfg, cfg)}>'
+            add(r.setdefault('by_cfg', {}).setdefault(name, blank(name)), flops, e0, e1, kind, probe)
     return out
 
 
@@ -397,15 +433,20 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
         phase = _prof['count'] % _prof['every']
         # algorithmic (fp32-equivalent) FLOPs; the kernel issues 3 fp16 products per multiply.  Two kinds of
         # samples, on DIFFERENT launches (timing a kernel through hipExtLaunchKernelGGL adds packets around it):
+        if phase == 0 or phase == _prof['every'] // 2:
+            cfg = lib.t2h_gemm_split_tile_config(ctypes.byref(g))
         if phase == 0:
-            # (k0, k1) receive the kernel's OWN start / end (t2h_gemm_split_time_next_launch): kernel time
+            # (k0, k1) receive the kernel's OWN start / end (t2h_gemm_split_time_next_launch): kernel time; the same
+            # launch stores its phase stamps (main loop duration + the shader clock it ran at)
             k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             k0.record()  # (creates the hipEvent_t handles the hook hands to the launch)
             k1.record()
+            stamps = torch.zeros(16 * (-(-M // 128)) * (-(-N // 64)), dtype=torch.int64, device=a_split.device)
             check(lib.t2h_gemm_split_time_next_launch(ctypes.c_void_p(k0.cuda_event), ctypes.c_void_p(k1.cuda_event)),
                   't2h_gemm_split_time_next_launch')
+            check(lib.t2h_gemm_split_probe_next_launch(_p(stamps)), 't2h_gemm_split_probe_next_launch')
             check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
-            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, k0, k1, 'kernel'))
+            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, k0, k1, 'kernel', cfg, stamps))
             return out if out is not None else out_split
         if phase == _prof['every'] // 2:
             # (e0, e1) are recorded on the stream around the launch and so run from the end of the previous
@@ -414,7 +455,7 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
             e0.record()
             check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
             e1.record()
-            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, e0, e1, 'stream'))
+            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, e0, e1, 'stream', cfg, None))
             return out if out is not None else out_split
     check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
     return out if out is not None else out_split

@@ -104,6 +104,34 @@ def padded_tables(order, per_row, start, maxr):
     return rows_tbl, val_tbl
 
 
+class RoundTables:
+    """Host side of graph replay (engine.RoundGraph.run): the run's schedule as padded tables plus the round
+    cursor the captured graph advances.  `advance()` is the CPU statement of t2h_schedule_advance -- copy round
+    *ctr of the tables into the staging rows / values, then ctr += 1 -- so the bookkeeping (how many replays, what
+    each replay sees, that the padding only repeats rows of the same round) can be exercised without a GPU
+    (tests/test_schedule.py, the 2-rank gloo run of tests/test_bench_dist.py)."""
+
+    def __init__(self, order, per_row, start, maxr):
+        self.rows_tbl, self.val_tbl = padded_tables(order, per_row, start, maxr)
+        self.n_rounds, self.maxr = len(start) - 1, int(maxr)
+        self.ctr = 0
+
+    def advance(self):
+        if self.ctr >= self.n_rounds:
+            raise IndexError(f'round cursor {self.ctr} past the {self.n_rounds} rounds of this run')
+        r = self.ctr
+        self.ctr += 1
+        return self.rows_tbl[r].copy(), self.val_tbl[r].copy()
+
+    def replay(self, body, first_eager=True):
+        """The launch pattern of RoundGraph.run: round 0 eagerly on the run that captures (first_eager), then one
+        replay per remaining round; body(rows, values) is called once per round.  -> number of replays."""
+        self.ctr = 0
+        for _ in range(self.n_rounds):
+            body(*self.advance())
+        return self.n_rounds - (1 if first_eager and self.n_rounds else 0)
+
+
 def stats(round_steps, steps):
     """Evaluation counts for the bench line: (sample, step) pairs the reference evaluates, pairs that
     change a token (the ones whose logits are read), rounds launched."""

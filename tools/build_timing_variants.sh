@@ -15,3 +15,6 @@ build nomma -DT2H_SDBG_NOMMA
 build nofrag -DT2H_SDBG_NOFRAG
 wait
 ls -la tools/_tb
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-comment -Iinclude -DT2H_MHA_TIMING \
+    text2human_amd/csrc/api.hip text2human_amd/csrc/attention.hip -o tools/_tb/mha_timing.so
+ls -la tools/_tb

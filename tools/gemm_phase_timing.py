@@ -58,8 +58,7 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
     for cfg in CFGS:
         lib.t2h_gemm_split_force_config(cfg)
         tb = torch.zeros(16 * 4096, dtype=torch.int64, device='cuda')
-        setter = lib.t2h_debug_set_gemm1_timing_buffer
-        setter(ctypes.c_void_p(0))
+        setter = lib.t2h_gemm_split_probe_next_launch
         for _ in range(3):
             assert lib.t2h_gemm_split_f32(ctypes.byref(g), st) == 0, name
         torch.cuda.synchronize()
@@ -73,7 +72,6 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
         setter(ctypes.c_void_p(tb.data_ptr()))
         lib.t2h_gemm_split_f32(ctypes.byref(g), st)
         torch.cuda.synchronize()
-        setter(ctypes.c_void_p(0))
         raw = tb.view(-1, 16).cpu()
         raw = raw[raw[:, 0] != 0].double()
         t = raw[:, :8] * 0.01  # us

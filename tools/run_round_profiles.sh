@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-end measurement batch on the GPU box (run through gpurun from the repo root):
-#   bench lines of the three configurations, rocprofv3 kernel traces of the same command (full 256
-#   sampling steps), the three separate --pmc passes of the parsing configuration, the micro-benchmarks
-#   behind DESIGN.md's tables.  Everything lands in gpurun_out/round/; copy what is to be judged to
-#   profiles/r04_* (tools/rocprof_summary.py / tools/pmc_summary.py stamp the kernel-source digest).
+#   the bench line, rocprofv3 kernel traces of the same command for the three configurations (full 256 sampling
+#   steps, the default path: every round one hipGraph replay), the three separate --pmc passes of EACH configuration,
+#   the micro-benchmarks behind DESIGN.md's tables.  Everything lands in gpurun_out/round/; copy what is to be judged
+#   to profiles/r04_* (tools/rocprof_summary.py / tools/pmc_summary.py stamp the kernel-source digest).
 set -u
 REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/round
@@ -19,9 +19,12 @@ for cfg in parsing pose hires; do
   python tools/rocprof_summary.py $db $OUT/bench_${cfg}_kernel_stats.md > /dev/null
   rm -rf $OUT/prof_$cfg
 done
-bash tools/run_pmc_bench.sh > $OUT/pmc.log 2>&1
-cp gpurun_out/pmc_summary_new.md gpurun_out/pmc_summary_new.json $OUT/ 2>/dev/null
-rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_SQ_VALU_MFMA_BUSY_CYCLES
+for cfg in parsing pose hires; do
+  bash tools/run_pmc_bench.sh $cfg >> $OUT/pmc.log 2>&1
+done
+cp gpurun_out/pmc_summary_new*.md gpurun_out/pmc_summary_new*.json $OUT/ 2>/dev/null
 python tools/sampler_gemm_bench.py 8 -1,8,10 7 > $OUT/sampler_gemm_bench_b8.log 2>&1
 python tools/mha_bench.py > $OUT/mha_bench.log 2>&1
+T2H_TIMING_SO=tools/_tb/none.so python tools/gemm_phase_timing.py 6,8,10 8 > $OUT/gemm_phase_timing_b8.log 2>&1
+T2H_TIMING_SO=tools/_tb/mha_timing.so python tools/mha_phase_timing.py 8 > $OUT/mha_phase_timing_b8.log 2>&1
 ls -la $OUT
