@@ -296,6 +296,9 @@ typedef struct t2h_sample_heads_args {
   const int32_t* expo_slot;
   const uint64_t* philox_seed_dev; /* if set, the seed is read from device memory (a captured launch sequence
                                       replayed for runs with different seeds); else philox_seed */
+  const int32_t* rng_rows;         /* optional, with row_philox_offset: rng_rows[i] = the row of the reference's
+                                      [n, n_class] exponential_ tensor whose elements rows[i] draws (a host that
+                                      reorders the samples of a batch keeps every row's own noise); NULL = rows[i] */
 } t2h_sample_heads_args;
 /* dst[i] = src[rows[i]], rows of row_bytes (multiple of 16) bytes */
 int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, int32_t n_rows, int32_t row_bytes, void* stream);

@@ -280,3 +280,30 @@ def test_decoder_attention_flash_fallback_matches_the_materialised_default(model
     img_b, _ = model.decode_indices([t.to(DEV) for t in top])
     assert (img_a - img_b).abs().max().item() < 2e-4
     assert not torch.equal(img_a, img_b)     # (another kernel really ran)
+
+
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_finished_samples_leave_the_batch_same_tokens(model, monkeypatch, graph):
+    """T2H_SHRINK_BATCH (default on): the samples are reordered by their number of rounds (schedule.leave_order) and
+    the transformer of a round runs on the samples that still have a step left -- a prefix of the reordered batch;
+    every row keeps its own element of the reference's noise tensors (t2h_sample_heads_args.rng_rows).  Tokens, in
+    the caller's sample order, and the final generator offset equal the full-batch schedule's, launch by launch and
+    as per-k captured graphs."""
+    from text2human_amd import engine
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    model.feed_data(synthetic.parsing_batch(5, seed=43))
+    tex_tok = model._texture_tokens(model.texture_mask)
+    monkeypatch.setenv('T2H_GRAPH', graph)
+
+    def run(seed, shrink):
+        monkeypatch.setenv('T2H_SHRINK_BATCH', '1' if shrink else '0')
+        torch.cuda.manual_seed_all(seed)
+        out = engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, 128, model.mask_id).clone()
+        return out, gen.get_offset(), dict(model.sampler_fn.last_stats)
+
+    for seed in (3, 4):
+        want, off_w, st_w = run(seed, False)
+        got, off_g, st_g = run(seed, True)
+        assert torch.equal(got, want) and off_g == off_w, seed
+        assert st_g['sample_steps_launched'] == st_g['sample_steps_needed'] <= st_w['sample_steps_launched']
+    assert st_g['sample_steps_launched'] < st_w['sample_steps_launched']   # (128 steps, 5 samples: somebody finishes early)

@@ -120,3 +120,24 @@ def test_round_tables_replay_visits_every_row_in_its_own_round():
     assert (seen == 1).all()
     with pytest.raises(IndexError):
         tb.advance()
+
+
+@pytest.mark.parametrize('B,T,steps', [(8, 512, 256), (32, 512, 256), (5, 64, 9)])
+def test_leave_order_makes_the_running_samples_a_prefix(B, T, steps):
+    """schedule.leave_order: with the samples sorted by their number of rounds, the samples still running in round r
+    are the first k_r of the batch, k_r never grows, and the (sample, round) pairs run = the pairs that change a token."""
+    step = _random_schedule(B, T, steps, seed=B + steps)
+    perm, n_act = schedule.leave_order(step, B, T)
+    assert sorted(perm.tolist()) == list(range(B)) and (np.diff(n_act) <= 0).all()
+    orig_row = (perm[:, None] * T + np.arange(T)[None, :]).reshape(-1)
+    order, start, round_steps = schedule.group_rounds(step[orig_row], B, T, compact=True)
+    active = (round_steps > 0).sum(1)
+    assert (np.diff(active) <= 0).all() and active[0] == B and active[-1] >= 1
+    for r in range(len(active)):
+        assert (round_steps[r, :active[r]] > 0).all() and (round_steps[r, active[r]:] == 0).all()
+        rows = order[start[r]:start[r + 1]]
+        assert (rows // T < active[r]).all()                      # a round only lists rows of running samples
+    st = schedule.stats(round_steps, steps, active)
+    assert st['sample_steps_launched'] == st['sample_steps_needed'] <= st['rounds'] * B
+    if steps == 256:
+        assert st['sample_steps_launched'] < st['rounds'] * B       # somebody finishes before the slowest sample

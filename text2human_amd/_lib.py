@@ -58,6 +58,7 @@ class SampleHeadsArgs(ctypes.Structure):
         ('philox_seed', ctypes.c_uint64), ('philox_offset', ctypes.c_uint64 * MAX_HEADS),
         ('philox_grid_threads', ctypes.c_uint32),
         ('row_philox_offset', c_vp), ('expo_rows', c_vp), ('expo_slot', c_vp), ('philox_seed_dev', c_vp),
+        ('rng_rows', c_vp),
     ]
 
 

@@ -508,12 +508,15 @@ __global__ __launch_bounds__(SH_THREADS) void sample_pick_kernel(const t2h_sampl
                                             : a.expo[head] + (int64_t)row * a.n_class;
   const uint64_t poff = a.row_philox_offset ? a.row_philox_offset[slot] : a.philox_offset[head];
   const uint64_t pseed = a.philox_seed_dev ? *a.philox_seed_dev : a.philox_seed;
+  // the element of the reference's [n, n_class] draw this row owns: its row THERE (the host may have reordered the
+  // samples of the batch, rng_rows) -- by default the row itself
+  const int rng_row = a.rng_rows ? a.rng_rows[slot] : row;
   float best = -1.f;
   int best_j = 0x7fffffff;
   for (int j = tid; j < a.n_class; j += SH_THREADS) {
     const float q = er ? er[j]
                        : torch_exponential_at(pseed, poff, a.philox_grid_threads,
-                                              (uint64_t)row * a.n_class + j);
+                                              (uint64_t)rng_row * a.n_class + j);
     const float sc = expf(lg[j] - mx) / q;
     if (sc > best) {
       best = sc;

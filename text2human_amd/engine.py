@@ -217,11 +217,21 @@ class SamplerNet:
     # (tests/test_gpu_edge_cases.py compares the tokens of both forms on the bench configuration).
     TRIM_MAX_ROWS = 256
 
-    def hidden(self, idx, segm_tok, tex_tok, defer_tail=False):
+    def hidden(self, idx, segm_tok, tex_tok, defer_tail=False, active=None):
+        """active = k < B: only the first k samples of the batch, on the first k * T rows of the SAME buffers
+        (samples never interact: attention is per sample) -- the samples of a compact schedule that have no step
+        left sit at the end of the batch (schedule.leave_order) and are not evaluated."""
         P, nm = self.P, self.name
         B, T = idx.shape
         C = self.desc['C']
-        buf = self._buffers(B * T, C, idx.device)
+        full = buf = self._buffers(B * T, C, idx.device)
+        if self.split and self.split_mha and tuple(full['vt'].shape) != (B, self.n_head, 2, C // self.n_head, T):
+            full['vt'] = ops.vt_empty(B, self.n_head, T, idx.device, C // self.n_head)
+        if active is not None and 0 < active < B:
+            k = int(active)
+            buf = {name: (v[:k] if name == 'vt' else v[:k * T]) for name, v in full.items()
+                   if name not in ('xc', 'yc', 'hc', 'uc')}
+            idx, segm_tok, tex_tok, B = idx[:k], segm_tok[:k], tex_tok[:k], k
         x, h, qkv, y, u = buf['x'], buf['h'], buf['qkv'], buf['y'], buf['u']
         ops.embed_sum4(idx, segm_tok, tex_tok, P[f'{nm}.tok_emb'], P[f'{nm}.pos_emb'],
                        P[f'{nm}.segm_emb'], P[f'{nm}.tex_emb'], out=x)
@@ -236,8 +246,6 @@ class SamplerNet:
             hs, ys, us, qks = buf['h_split'], buf['y_split'], buf['u_split'], buf['qk_split']
             vt = buf['vt']
             hd = C // self.n_head
-            if self.split_mha and tuple(vt.shape) != (B, self.n_head, 2, hd, T):
-                vt = buf['vt'] = ops.vt_empty(B, self.n_head, T, idx.device, hd)
             for i in range(L):
                 p = f'{nm}.{i}'
                 ops.layernorm_split(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs)
@@ -249,7 +257,9 @@ class SamplerNet:
                     ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out=qkv, bias=P[f'{p}.qkv.b'])
                     ops.mha_noncausal_split(qkv, B, T, self.n_head, ys)
                 if i == L - 1 and defer_tail:
-                    self._deferred = (x, ys, M, C)
+                    # (the WHOLE batch's buffers: finish_tail addresses rows by their index in the batch; only
+                    # the first M rows -- the active samples -- were evaluated, and only they are listed)
+                    self._deferred = (full['x'], full['y_split'], M, C)
                     return x
                 ops.gemm_split(ys, P[f'{p}.proj.w_split'], M, C, C, out=x, bias=P[f'{p}.proj.b'], residual=x)
                 ops.layernorm_split(x, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs)
@@ -271,11 +281,11 @@ class SamplerNet:
     def finish_tail(self, rows, n_rows):
         """After hidden(..., defer_tail=True): the last layer's row-wise tail.  Returns (hidden, compact):
         compact=True -> hidden[i] is row rows[i] (only the first n_rows rows of the list were evaluated)."""
-        x, ys, M, C = self._deferred
+        x, ys, M, C = self._deferred   # (x, ys: the whole batch's buffers; M: the rows that were evaluated)
         self._deferred = None
         P = self.P
         p = f"{self.name}.{self.desc['n_layers'] - 1}"
-        buf = self._buffers(M, C, x.device)
+        buf = self._buffers(x.shape[0], C, x.device)
         if 0 < n_rows <= self.TRIM_MAX_ROWS:
             m = int(n_rows)
             xc, yc = ops.gather_rows(x, rows, m, out=buf['xc'][:m]), ops.gather_rows(ys, rows, m, out=buf['yc'][:m])
@@ -378,22 +388,27 @@ class SampleSchedule:
     rows[start[r]:start[r + 1]], each with its own noise reference."""
 
     def __init__(self, rows, start, round_steps, noise_kind, seed=None, offsets=None, expo_rows=None, slots=None,
-                 host=None):
+                 host=None, perm=None, rng_rows=None, active=None):
         self.rows, self.start, self.round_steps = rows, start, round_steps
-        self.host = host  # (row order, per-row offsets) as numpy, for the padded tables of the graph path
+        self.host = host  # (row order, per-row offsets[, rng rows]) as numpy, for the padded tables of the graph path
+        # finished samples leave the batch (schedule.leave_order): perm[new position] = original sample, rows /
+        # round_steps are in the NEW order, rng_rows = the original row of every listed row (its noise), active[r] =
+        # samples still running in round r (a prefix of the reordered batch)
+        self.perm, self.rng_rows, self.active = perm, rng_rows, active
         self.noise_kind, self.seed, self.offsets, self.expo_rows, self.slots = noise_kind, seed, offsets, expo_rows, slots
         self.n_rounds = len(start) - 1
         self.max_rows = int(max(int(start[r + 1] - start[r]) for r in range(self.n_rounds))) if self.n_rounds else 0
 
     def row_noise(self, lo, hi):
         if self.noise_kind == 'philox':
-            return ('philox', self.seed, self.offsets[lo:hi])
+            return ('philox', self.seed, self.offsets[lo:hi], self.rng_rows[lo:hi] if self.rng_rows is not None else None)
         return ('explicit', self.expo_rows, self.slots[lo:hi])
 
 
-def build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact=True):
+def build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact=True, shrink=False):
     """The unmasking schedule + RNG bookkeeping of one sample_fn call (schedule.py), consuming
-    `noise` exactly as the reference's loop would (models/sample_model.py:279-306)."""
+    `noise` exactly as the reference's loop would (models/sample_model.py:279-306).  shrink (compact rounds on the
+    device generator only): the samples are reordered so that finished ones leave the batch (SampleSchedule.perm)."""
     B, T = tex_tok.shape
     dev = tex_tok.device
     n = B * T
@@ -413,11 +428,26 @@ def build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact=True)
         head_mask = mask_dev.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         _, expo_off, final = schedule.draw_offsets(head_mask, sample_steps, off0, rand_inc, expo_inc, n_books)
         gen.set_offset(final)  # where the reference's generator stands after its loop
+        perm = rng_rows = rng_dev = active = None
+        if shrink and compact and B > 1:
+            perm, _ = schedule.leave_order(step_of_row, B, T)
+            if (perm == np.arange(B)).all():
+                perm = None
+        if perm is not None:
+            orig_row = (perm[:, None] * T + np.arange(T)[None, :]).reshape(-1)  # original row of every reordered row
+            step_of_row, tex_host = step_of_row[orig_row], tex_host[orig_row]
         order, start, round_steps = schedule.group_rounds(step_of_row, B, T, compact)
         offs = expo_off[step_of_row[order], tex_host[order]]
         assert (offs >= 0).all()
+        if shrink and compact:
+            active = (round_steps > 0).sum(1).astype(np.int64)
+            assert all((round_steps[r, :active[r]] > 0).all() for r in range(len(active)))  # a prefix of the batch
+        if perm is not None:
+            rng_rows = orig_row[order].astype(np.int32)
+            rng_dev = torch.from_numpy(rng_rows).to(dev)
         return SampleSchedule(torch.from_numpy(order.astype(np.int32)).to(dev), start, round_steps, 'philox', seed=seed,
-                              offsets=torch.from_numpy(offs).to(dev), host=(order, offs))
+                              offsets=torch.from_numpy(offs).to(dev), host=(order, offs, rng_rows), perm=perm,
+                              rng_rows=rng_dev, active=active)
     # explicit draws (tests replaying CPU noise; the emulation fallback): the reference's own loop
     # order, with the rows each head needs copied out of its full draw
     unmasked = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -465,61 +495,72 @@ class RoundGraph:
         self._net = weakref.ref(net)
         self.maxr, self.temp, self.mask_id = maxr, float(temp), mask_id
         self.x_t, self.out, self.segm, self.tex = i64(B, T), i64(n_books, B * T), i64(B, T), i64(B, T)
-        self.rows_tbl, self.offs_tbl = i32(steps, maxr), i64(steps, maxr)
-        self.cur_rows, self.cur_offs = i32(maxr), i64(maxr)
+        self.rows_tbl, self.offs_tbl, self.rng_tbl = i32(steps, maxr), i64(steps, maxr), i32(steps, maxr)
+        self.cur_rows, self.cur_offs, self.cur_rng = i32(maxr), i64(maxr), i32(maxr)
         self.round_ctr, self.seed = i32(1), i64(1)
         self.logits_ws = torch.empty((maxr, n_class), dtype=torch.float32, device=dev)
         self.stream = torch.cuda.Stream(device=dev)
-        self.graph = None
+        self.B = B
+        self.graphs = {}  # samples still running (a prefix of the batch, schedule.leave_order) -> captured round
 
-    def body(self):
+    def body(self, k):
+        """One round on the first k samples of the batch (the others have no step left)."""
         net = self._net()
         P, nm = net.P, net.name
-        ops.schedule_advance(self.rows_tbl, self.offs_tbl, None, self.round_ctr, self.cur_rows, self.cur_offs, None,
-                             self.maxr)
-        net.hidden(self.x_t, self.segm, self.tex, defer_tail=True)
+        ops.schedule_advance(self.rows_tbl, self.offs_tbl, self.rng_tbl, self.round_ctr, self.cur_rows, self.cur_offs,
+                             self.cur_rng, self.maxr)
+        net.hidden(self.x_t, self.segm, self.tex, defer_tail=True, active=k)
         hidden, compact = net.finish_tail(self.cur_rows, self.maxr)
         ops.sample_heads(hidden, P[f'{nm}.ln_f.g'], P[f'{nm}.ln_f.b'], P[f'{nm}.heads'], {}, self.cur_rows, self.maxr,
                          self.tex.view(-1), self.temp, self.x_t, self.out,
-                         row_noise=('philox', self.seed, self.cur_offs), hidden_compact=compact, logits_ws=self.logits_ws)
+                         row_noise=('philox', self.seed, self.cur_offs, self.cur_rng), hidden_compact=compact,
+                         logits_ws=self.logits_ws)
+
+    def capture(self, k):
+        g = torch.cuda.CUDAGraph()
+        # thread_local: another thread of this process -- RCCL's watchdog, a data loader -- may call into
+        # the HIP runtime while this thread captures.  No cyclic garbage collection inside the capture:
+        # a collected tensor / graph / event would be released through the runtime in the middle of it.
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
+                self.body(k)
+        finally:
+            if gc_was_on:
+                gc.enable()
+        self.graphs[k] = g
 
     def run(self, sched, segm_tok, tex_tok):
         """All rounds of one run on this graph's stream; returns `out` (valid once the caller's stream
         has waited, which this does)."""
-        order, offs = sched.host
-        tables = schedule.RoundTables(order, offs, sched.start, self.maxr)
+        order, offs, rng_rows = sched.host
+        tables = schedule.RoundTables(order, offs, sched.start, self.maxr, per_row32=rng_rows if rng_rows is not None else order)
         R, rows_tbl, offs_tbl = tables.n_rounds, tables.rows_tbl, tables.val_tbl
+        active = sched.active if sched.active is not None else np.full(R, self.B, dtype=np.int64)
         caller = torch.cuda.current_stream()
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
             ops.split_overflow(reset=True)  # (this stream's flag; allocated here, before any capture)
             self.rows_tbl[:R].copy_(torch.from_numpy(rows_tbl), non_blocking=False)
             self.offs_tbl[:R].copy_(torch.from_numpy(offs_tbl), non_blocking=False)
+            self.rng_tbl[:R].copy_(torch.from_numpy(tables.aux32_tbl), non_blocking=False)
             self.segm.copy_(segm_tok)
             self.tex.copy_(tex_tok)
             self.x_t.fill_(self.mask_id)
             self.out.fill_(-1)
             self.round_ctr.zero_()
             self.seed.fill_(schedule.as_int64(sched.seed))  # (a uint64 seed >= 2^63 in its two's-complement form)
-            first = 0
-            if self.graph is None:
-                self.body()  # round 0 eagerly: sizes every cached buffer before the capture
-                first = 1
-                g = torch.cuda.CUDAGraph()
-                # thread_local: another thread of this process -- RCCL's watchdog, a data loader -- may call into
-                # the HIP runtime while this thread captures.  No cyclic garbage collection inside the capture:
-                # a collected tensor / graph / event would be released through the runtime in the middle of it.
-                gc_was_on = gc.isenabled()
-                gc.disable()
-                try:
-                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
-                        self.body()
-                finally:
-                    if gc_was_on:
-                        gc.enable()
-                self.graph = g
-            for _ in range(first, R):
-                self.graph.replay()
+            for r in range(R):
+                k = int(active[r])
+                g = self.graphs.get(k)
+                if g is not None:
+                    g.replay()
+                else:
+                    # the first round with k running samples: eagerly (it also sizes every cached buffer), then the
+                    # capture -- which executes nothing: the device-side round cursor stands where the eager round left it
+                    self.body(k)
+                    self.capture(k)
             check_split_overflow('index sampler')
         caller.wait_stream(self.stream)
         return self.out
@@ -558,8 +599,21 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     n = B * T
     n_class = P[f'{nm}.heads'].shape[1]
     tex_flat = tex_tok.reshape(-1).contiguous()
-    sched = build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact)
-    net.last_stats = schedule.stats(sched.round_steps, sample_steps)
+    # finished samples leave the batch (T2H_SHRINK_BATCH=0 opts out; hooks see the batch in its own order)
+    shrink = (compact and step_hook is None and round_hook is None and os.environ.get('T2H_SHRINK_BATCH', '1') != '0')
+    sched = build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact, shrink)
+    net.last_stats = schedule.stats(sched.round_steps, sample_steps, sched.active)
+    if sched.perm is not None:
+        perm_t = torch.from_numpy(sched.perm).to(dev)
+        segm_tok, tex_tok = segm_tok[perm_t].contiguous(), tex_tok[perm_t].contiguous()
+        tex_flat = tex_tok.reshape(-1)
+
+    def in_batch_order(out):  # [n_books, n] in the schedule's sample order -> the caller's
+        if sched.perm is None:
+            return out
+        inv = torch.from_numpy(np.argsort(sched.perm)).to(dev)
+        return out.view(out.shape[0], B, T)[:, inv].reshape(out.shape[0], n).contiguous()
+
     defer = bool(split and getattr(net, 'split_mha', False) and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
     # Default (T2H_GRAPH=0 opts out): every round is ONE replay of a captured launch sequence (RoundGraph)
     # instead of ~180 launches from this thread.  The GPU work is the same; what changes is the host side --
@@ -575,13 +629,15 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
         key = (B, T, sample_steps, maxr, float(temp), int(mask_id), n_books)
         if key not in net._graphs:
             net._graphs[key] = RoundGraph(net, B, T, sample_steps, maxr, n_books, n_class, temp, mask_id, dev)
-        return net._graphs[key].run(sched, segm_tok, tex_tok).clone()
+        return in_batch_order(net._graphs[key].run(sched, segm_tok, tex_tok).clone())
     x_t = torch.full((B, T), mask_id, dtype=torch.int64, device=dev)
     out = torch.full((n_books, n), -1, dtype=torch.int64, device=dev)
     logits_ws = torch.empty((max(sched.max_rows, 1), n_class), dtype=torch.float32, device=dev)
     for r in range(sched.n_rounds):
         lo, hi = int(sched.start[r]), int(sched.start[r + 1])
-        hidden = net.hidden(x_t, segm_tok, tex_tok, defer_tail=True) if defer else net.hidden(x_t, segm_tok, tex_tok)
+        k = int(sched.active[r]) if sched.active is not None else None
+        hidden = (net.hidden(x_t, segm_tok, tex_tok, defer_tail=True, active=k) if defer
+                  else net.hidden(x_t, segm_tok, tex_tok))
         rows_r = sched.rows[lo:hi]
         hidden_compact = False
         if defer:
@@ -595,7 +651,7 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
             step_hook(int(sched.round_steps[r].max()), x_t, out)
     if split:
         check_split_overflow('index sampler')
-    return out
+    return in_batch_order(out)
 
 
 # ---------------------------------------------------------------- UNet + heads

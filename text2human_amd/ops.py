@@ -669,7 +669,8 @@ def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex,
     out_idx [n_heads, n].  philox = (seed, {head: generator offset}): the noise of the listed heads is
     computed in the kernel as the corresponding elements of torch's full-tensor exponential_ draws
     instead of being read from expo_by_head.  row_noise (row lists that mix sampling steps):
-    ('philox', seed, offsets int64 [>= n_rows]) = per-listed-row generator offsets, or
+    ('philox', seed, offsets int64 [>= n_rows][, rng_rows int32 [>= n_rows]]) = per-listed-row generator offsets (and
+    the rows of the reference's draw they belong to, if the samples were reordered), or
     ('explicit', expo_rows f32 [*, n_class], slots int32 [>= n_rows]) = per-listed-row explicit draws."""
     _chk_f32(hidden, lnf_g, lnf_b, w_heads, *expo_by_head.values())
     if int(n_rows) == 0:
@@ -696,9 +697,13 @@ def sample_heads(hidden, lnf_g, lnf_b, w_heads, expo_by_head, rows, n_rows, tex,
         a.logits_ws = ws.data_ptr()
     if row_noise is not None:
         if row_noise[0] == 'philox':
-            _, seed, offs = row_noise
+            _, seed, offs = row_noise[:3]
             assert offs.dtype == torch.int64 and offs.is_cuda and offs.numel() >= int(n_rows)
             a.row_philox_offset = offs.data_ptr()
+            if len(row_noise) > 3 and row_noise[3] is not None:  # rows of the reference's draw (reordered samples)
+                rr = row_noise[3]
+                assert rr.dtype == torch.int32 and rr.is_cuda and rr.numel() >= int(n_rows)
+                a.rng_rows = rr.data_ptr()
             if torch.is_tensor(seed):  # the seed lives in device memory (graph replay)
                 assert seed.dtype == torch.int64 and seed.is_cuda and seed.numel() == 1
                 a.philox_seed_dev = seed.data_ptr()
