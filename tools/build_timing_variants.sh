@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/_tb
 build() {  # name, extra -D flags
   name=$1; shift
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-comment -Wno-pass-failed -Iinclude -DT2H_GEMM_TIMING "$@" \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-comment -Wno-pass-failed -Iinclude "$@" \
       text2human_amd/csrc/api.hip text2human_amd/csrc/gemm_split.hip -o tools/_tb/$name.so &
 }
 build none

@@ -1,7 +1,9 @@
-"""Where does a split-GEMM launch spend its time?  Debug build (-DT2H_GEMM_TIMING) with
-s_memrealtime stamps (100 MHz) per workgroup: entry, prologue done, main loop done, epilogue
-stores issued, stores acknowledged.  Prints the median phase lengths, the dispatch skew and the
-span first-entry -> last-ack next to the event-timed launch.  GPU only.
+"""Where does a split-GEMM launch spend its time, and at which clock?  Phase stamps of
+t2h_gemm_split_probe_next_launch (s_memrealtime at 100 MHz + s_memtime = shader clock, per workgroup): entry,
+prologue done, main loop done, epilogue stores issued.  Prints the median phase lengths, the dispatch skew, the
+span first-entry -> last stamp next to the event-timed launch, and the shader clock of each phase.  Runs on the
+product library; ablation builds (T2H_TIMING_DEFS / T2H_TIMING_SO) drop the DMA, the matrix instructions or the
+fragment reads.  GPU only.
 
     python tools/gemm_phase_timing.py [cfgs=6,8] [batch=8]
 """
@@ -18,15 +20,18 @@ sys.path.insert(0, ROOT)
 from text2human_amd._lib import GemmSplitArgs  # noqa: E402
 
 csrc = os.path.join(ROOT, 'text2human_amd', 'csrc')
-so = '/tmp/libt2h_gemm_timing.so'
-DEFS = [d for d in os.environ.get('T2H_TIMING_DEFS', '').split(',') if d]  # e.g. T2H_SDBG_NOPUT,T2H_SDBG_NOGLOAD
-PREBUILT = os.environ.get('T2H_TIMING_SO')  # a debug build made in the build container (tools/build_timing_variants.sh)
+DEFS = [d for d in os.environ.get('T2H_TIMING_DEFS', '').split(',') if d]  # ablation builds, e.g. T2H_SDBG_NOGLOAD,T2H_SDBG_NOMMA
+PREBUILT = os.environ.get('T2H_TIMING_SO')  # an ablation build made in the build container (tools/build_timing_variants.sh)
 if PREBUILT:
     so = os.path.join(ROOT, PREBUILT)
+elif not DEFS and not os.environ.get('T2H_DMA_POLICY'):
+    so = os.path.join(ROOT, 'text2human_amd', 'libt2h_hip.so')  # the product library carries the phase stamps
 else:
-  subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-comment',
-                f'-I{ROOT}/include', '-DT2H_GEMM_TIMING', *[f'-D{d}' for d in DEFS], *(["-DT2H_DMA_POLICY=\" " + os.environ['T2H_DMA_POLICY'].replace('-', '') + "\""] if os.environ.get('T2H_DMA_POLICY') else []), os.path.join(csrc, 'api.hip'),
-                os.path.join(csrc, 'gemm_split.hip'), '-o', so], check=True)
+    so = '/tmp/libt2h_gemm_timing.so'
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-comment', f'-I{ROOT}/include',
+                    *[f'-D{d}' for d in DEFS],
+                    *(["-DT2H_DMA_POLICY=\" " + os.environ['T2H_DMA_POLICY'].replace('-', '') + "\""] if os.environ.get('T2H_DMA_POLICY') else []),
+                    os.path.join(csrc, 'api.hip'), os.path.join(csrc, 'gemm_split.hip'), '-o', so], check=True)
 lib = ctypes.CDLL(so)
 CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 else [6, 8]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -83,8 +88,8 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
         print(f'{name:8s} cfg{cfg:2d}: launch {t_evt:6.1f} us | {nb:4d} blocks | entry skew med {med(t[:, 0] - first):5.2f} '
               f'max {(t[:, 0] - first).max().item():5.2f} | prologue {med(t[:, 1] - t[:, 0]):5.2f} | main loop '
               f'{med(t[:, 2] - t[:, 1]):5.2f} (max {(t[:, 2] - t[:, 1]).max().item():5.2f}) | epilogue issue '
-              f'{med(t[:, 3] - t[:, 2]):5.2f} | store ack {med(t[:, 4] - t[:, 3]):5.2f} | first entry -> last ack '
-              f'{(t[:, 4].max().item() - first):6.2f} | last main-loop end {(t[:, 2].max().item() - first):6.2f} | shader clock GHz: '
+              f'{med(t[:, 3] - t[:, 2]):5.2f} | first entry -> last epilogue stamp '
+              f'{(t[:, 3].max().item() - first):6.2f} | last main-loop end {(t[:, 2].max().item() - first):6.2f} | shader clock GHz: '
               f'prologue {ghz(0, 1):.2f} main loop {ghz(1, 2):.2f} epilogue {ghz(2, 3):.2f}',
               flush=True)
     lib.t2h_gemm_split_force_config(-1)
