@@ -239,3 +239,27 @@ def test_gemm_split_at_the_b32_shapes_on_the_automatic_dispatch(N, K):
         full = torch.empty(M, N, device=DEV)
         ops.gemm_split(a_s, w_s, M, N, K, out=full, bias=b.to(DEV))
         assert torch.equal(vt.cpu(), _pack_vt_host(full[:, 2 * C:].contiguous().cpu(), B, T, H))
+
+
+def test_gelu_epilogue_rational_erf_against_exact_erf():
+    """fc1's GELU epilogue uses a rational erf (gemm_split.hip: erf_rational, max abs error 4e-7 on [-4, 4], clamped
+    outside) instead of erff.  Bounded here directly: a dense grid of pre-activations over [-9, 9] (fc1's range and
+    beyond the clamp) goes through the product epilogue via an identity weight matrix -- the three-product GEMM of a
+    22-bit operand with the identity is exact -- and is compared with nn.GELU()'s definition in fp64:
+    |gelu_hip - 0.5 x (1 + erf(x / sqrt 2))| <= 0.5 |x| * 4.5e-7 + the 2^-22 rounding of the split-row output."""
+    import math
+    M, K = 4096, 32
+    x = torch.linspace(-9.0, 9.0, M * K, dtype=torch.float64).view(M, K)
+    x = _unsplit(ops.pack_split_rows_host(x.float()), M, K)             # the 22-bit values the kernel sees
+    a_s, w_s = ops.split_rows(x.to(DEV)), ops.pack_split_rows_host(torch.eye(K)).to(DEV)
+    o_s = ops.split_rows_empty(M, K, DEV)
+    ops.gemm_split(a_s, w_s, M, K, K, out_split=o_s, act=ops.ACT_GELU)
+    o32 = torch.empty(M, K, device=DEV)
+    ops.gemm_split(a_s, w_s, M, K, K, out=o32, act=ops.ACT_GELU)
+    xd = x.double()
+    ref = 0.5 * xd * (1.0 + torch.erf(xd / math.sqrt(2.0)))
+    for got in (_unsplit(o_s.cpu(), M, K).double(), o32.cpu().double()):
+        err = (got - ref).abs()
+        bound = 0.5 * xd.abs() * 4.5e-7 + ref.abs() * 2.0**-21 + 1e-9
+        assert (err <= bound).all(), (err - bound).max().item()
+    assert (ref - o32.cpu().double()).abs().max().item() > 0            # (not the identity function by accident)
