@@ -240,7 +240,12 @@ def profile_side_data(kernel_label, config):
     if not kernel_label.startswith('gemm_split'):
         return out
     want = kernel_src_digest()
-    tag = '' if config == 'parsing' else f'_{config}'
+    # (parsing at 32 images per GPU runs the sampler GEMMs at the pose configuration's shapes, M = 16384: its rows are
+    # taken from that configuration's passes)
+    src_cfg = 'pose' if config == 'parsing_b32' else config
+    if src_cfg != config:
+        out['traffic_note'] = 'GEMM rows of the pose configuration (same sampler shapes, M = 16384)'
+    tag = '' if src_cfg == 'parsing' else f'_{src_cfg}'
     path = os.path.join(ROOT, 'profiles', f'r04_pmc_summary{tag}.json')
     if os.path.exists(path):
         d = json.load(open(path))
@@ -255,7 +260,7 @@ def profile_side_data(kernel_label, config):
                                           f'kernel sources {want})')
         else:
             out['traffic_note'] = f'profiles/{os.path.basename(path)} is from other kernel sources ({d.get("kernel_src_sha")} != {want})'
-    path = os.path.join(ROOT, 'profiles', f'r04_bench_{config}_kernel_stats.json')
+    path = os.path.join(ROOT, 'profiles', f'r04_bench_{src_cfg}_kernel_stats.json')
     if os.path.exists(path):
         d = json.load(open(path))
         if d.get('kernel_src_sha') == want:
