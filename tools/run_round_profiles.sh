@@ -25,6 +25,6 @@ done
 cp gpurun_out/pmc_summary_new*.md gpurun_out/pmc_summary_new*.json $OUT/ 2>/dev/null
 python tools/sampler_gemm_bench.py 8 -1,8,10 7 > $OUT/sampler_gemm_bench_b8.log 2>&1
 python tools/mha_bench.py > $OUT/mha_bench.log 2>&1
-T2H_TIMING_SO=tools/_tb/none.so python tools/gemm_phase_timing.py 6,8,10 8 > $OUT/gemm_phase_timing_b8.log 2>&1
+python tools/gemm_phase_timing.py 6,8,10 8 > $OUT/gemm_phase_timing_b8.log 2>&1
 T2H_TIMING_SO=tools/_tb/mha_timing.so python tools/mha_phase_timing.py 8 > $OUT/mha_phase_timing_b8.log 2>&1
 ls -la $OUT
