@@ -141,3 +141,59 @@ def test_leave_order_makes_the_running_samples_a_prefix(B, T, steps):
     assert st['sample_steps_launched'] == st['sample_steps_needed'] <= st['rounds'] * B
     if steps == 256:
         assert st['sample_steps_launched'] < st['rounds'] * B       # somebody finishes before the slowest sample
+
+
+def _toy_token(state_b, row_in_sample, draw_row, step, head):
+    """Stand-in for (transformer + categorical draw): depends on the WHOLE current state of the sample -- like
+    attention -- and on the identity of the noise element (the row of the reference's draw, the step, the head)."""
+    h = (int(state_b.sum()) * 1000003 + int((state_b * (np.arange(len(state_b)) + 1)).sum())) & 0x7FFFFFFF
+    return (h ^ (draw_row * 2654435761) ^ (step * 40503) ^ (head * 97)) % 1024
+
+
+def _reference_loop(step, tex, B, T, steps, mask_id):
+    """models/sample_model.py:279-317 with the toy model: every step, all samples, tokens of that step sampled from the
+    state BEFORE the step's writes."""
+    x = np.full((B, T), mask_id, dtype=np.int64)
+    for t in range(steps, 0, -1):
+        rows = np.nonzero(step == t)[0]
+        new = [(r, _toy_token(x[r // T], r % T, r, t, int(tex[r]))) for r in rows]
+        for r, v in new:
+            x[r // T, r % T] = v + 1024 * int(tex[r])
+    return x
+
+
+def _rounds_loop(step, tex, B, T, mask_id, shrink):
+    """engine.sample_tokens' host logic: (reordered) compact rounds; a round evaluates only the running prefix."""
+    perm = np.arange(B)
+    if shrink:
+        perm, _ = schedule.leave_order(step, B, T)
+    orig_row = (perm[:, None] * T + np.arange(T)[None, :]).reshape(-1)
+    step_p, tex_p = step[orig_row], tex[orig_row]
+    order, start, round_steps = schedule.group_rounds(step_p, B, T, compact=True)
+    active = (round_steps > 0).sum(1)
+    rng_rows = orig_row[order]
+    x = np.full((B, T), mask_id, dtype=np.int64)
+    for r in range(len(start) - 1):
+        lo, hi = int(start[r]), int(start[r + 1])
+        k = int(active[r]) if shrink else B
+        before = x.copy()                                   # the round's "hidden states": one evaluation, then writes
+        for i in range(lo, hi):
+            row = int(order[i])
+            assert row // T < k
+            x[row // T, row % T] = _toy_token(before[row // T], row % T, int(rng_rows[i]), int(step_p[row]),
+                                              int(tex_p[row])) + 1024 * int(tex_p[row])
+    return x[np.argsort(perm)]                              # back in the caller's order (engine.in_batch_order)
+
+
+@pytest.mark.parametrize('B,T,steps,seed', [(4, 32, 16, 0), (7, 16, 40, 1), (3, 64, 256, 2), (1, 8, 3, 3)])
+def test_compact_and_shrinking_rounds_give_the_reference_loops_tokens(B, T, steps, seed):
+    """With a toy model whose output depends on a sample's whole current state (and on which element of the reference's
+    noise tensor a row uses), the compact rounds -- with and without finished samples leaving the batch -- end in the
+    same tokens as the reference's synchronous loop: samples never interact, so each may walk its own steps."""
+    step = _random_schedule(B, T, steps, seed)
+    tex = np.random.default_rng(seed + 100).integers(0, 18, B * T)
+    want = _reference_loop(step, tex, B, T, steps, mask_id=18432)
+    assert (want != 18432).all()
+    for shrink in (False, True):
+        got = _rounds_loop(step, tex, B, T, 18432, shrink)
+        assert (got == want).all(), f'shrink={shrink}'
