@@ -15,7 +15,7 @@ inputs resident in HBM before the timed region:
           32x16, nearest-x2 both quantised latents, fully-convolutional decode), batch 8 per GPU.
 
 The default run (`--config parsing`) also times, inside the same command, the other
-configurations for 1 warm-up + 2 steps each and reports them under "other_configs": configs[3]'s
+configurations for 1 warm-up + 5 steps each and reports them under "other_configs": configs[3]'s
 per-GPU share (sample_from_parsing at 32 images per GPU; its global batch at N = 8 IS configs[3]),
 and at N = 1 configs[2] (pose, B = 32) and configs[4]'s per-GPU share (hires, B = 8).
 
@@ -97,7 +97,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-eager-leg', action='store_true',
                     help='skip the individual-launches leg (T2H_GRAPH=0 + HIP-event sampling of the GEMM launches) '
                          'that the roofline object comes from')
-    ap.add_argument('--other-steps', type=int, default=2, help='timed steps of each other_configs leg (after 1 warm-up)')
+    ap.add_argument('--other-steps', type=int, default=5, help='timed steps of each other_configs leg (after 1 warm-up)')
+    ap.add_argument('--eager-steps', type=int, default=2, help='steps of the individual-launches leg (after 1 warm-up)')
     ap.add_argument('--eager-gpu-baseline', action='store_true',
                     help='also time the oracle sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
     ap.add_argument('--stub-model', action='store_true',
@@ -246,29 +247,40 @@ def profile_side_data(kernel_label, config):
     if src_cfg != config:
         out['traffic_note'] = 'GEMM rows of the pose configuration (same sampler shapes, M = 16384)'
     tag = '' if src_cfg == 'parsing' else f'_{src_cfg}'
-    path = os.path.join(ROOT, 'profiles', f'r04_pmc_summary{tag}.json')
-    if os.path.exists(path):
+    rounds = ('r05', 'r04')  # newest first: the first summary taken from THIS tree's kernel sources is quoted
+    stale = None
+    for rnd in rounds:
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_summary{tag}.json')
+        if not os.path.exists(path):
+            continue
         d = json.load(open(path))
-        if d.get('kernel_src_sha') == want:
-            rows = [r for r in d['rows'] if r['kernel'].startswith('gemm_split')]
-            n = sum(r['launches'] for r in rows)
-            if n:
-                out.update(traffic=sum(r['traffic_mb'] * r['launches'] for r in rows) / n * 1e6,
-                           traffic_unit='bytes/launch',
-                           mfma_util_pmc=sum(r['mfma_util'] * r['launches'] for r in rows) / n,
-                           traffic_source=f'profiles/{os.path.basename(path)} (rocprofv3 --pmc, separate passes; '
-                                          f'kernel sources {want})')
-        else:
-            out['traffic_note'] = f'profiles/{os.path.basename(path)} is from other kernel sources ({d.get("kernel_src_sha")} != {want})'
-    path = os.path.join(ROOT, 'profiles', f'r04_bench_{src_cfg}_kernel_stats.json')
-    if os.path.exists(path):
+        if d.get('kernel_src_sha') != want:
+            stale = stale or f'profiles/{os.path.basename(path)} is from other kernel sources ({d.get("kernel_src_sha")} != {want})'
+            continue
+        rows = [r for r in d['rows'] if r['kernel'].startswith('gemm_split')]
+        n = sum(r['launches'] for r in rows)
+        if n:
+            out.update(traffic=sum(r['traffic_mb'] * r['launches'] for r in rows) / n * 1e6,
+                       traffic_unit='bytes/launch',
+                       mfma_util_pmc=sum(r['mfma_util'] * r['launches'] for r in rows) / n,
+                       traffic_source=f'profiles/{os.path.basename(path)} (rocprofv3 --pmc, separate passes; '
+                                      f'kernel sources {want})')
+            break
+    if out['traffic'] is None and stale:
+        out['traffic_note'] = stale
+    for rnd in rounds:
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_bench_{src_cfg}_kernel_stats.json')
+        if not os.path.exists(path):
+            continue
         d = json.load(open(path))
-        if d.get('kernel_src_sha') == want:
-            rows = [r for r in d['rows'] if r['kernel'].startswith('gemm_split')]
-            n = sum(r['calls'] for r in rows)
-            if n:
-                out['avg_launch_us_rocprof'] = sum(r['avg_us'] * r['calls'] for r in rows) / n
-                out['rocprof_source'] = f'profiles/{os.path.basename(path)}'
+        if d.get('kernel_src_sha') != want:
+            continue
+        rows = [r for r in d['rows'] if r['kernel'].startswith('gemm_split')]
+        n = sum(r['calls'] for r in rows)
+        if n:
+            out['avg_launch_us_rocprof'] = sum(r['avg_us'] * r['calls'] for r in rows) / n
+            out['rocprof_source'] = f'profiles/{os.path.basename(path)}'
+            break
     return out
 
 
@@ -487,9 +499,16 @@ class ConfigRun:
         shard.barrier(dworld)
         sync()
         events = []
+        marks = []  # one event per step boundary (no sync inside the timed region): the spread of the steps
         t0 = time.perf_counter()
         for _ in range(steps):
+            if not self.stub:
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
             top, u8 = self.step(events)
+        if not self.stub:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
         sync()
         my_elapsed = time.perf_counter() - t0
         shard.barrier(dworld)
@@ -498,7 +517,10 @@ class ConfigRun:
         for name, e0, e1 in events:
             stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / steps
         net = getattr(self.model, 'sampler_fn', None)
+        step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
         return dict(elapsed=elapsed, my_elapsed=my_elapsed, top=top, u8=u8, stage_ms=stage_ms,
+                    step_ms_median=(step_ms[len(step_ms) // 2] if step_ms else None),
+                    step_ms_min_max=([step_ms[0], step_ms[-1]] if step_ms else None),
                     stats=getattr(net, 'last_stats', None), launch_mode=getattr(net, 'last_launch_mode', None))
 
     def eager_profile(self, steps):
@@ -585,6 +607,8 @@ def side_config(name, run, steps, warmup, batch_per_gpu, world, dworld, dev, pro
     out = {'metric': wl['metric'], 'value': batch_per_gpu * world * steps / r['elapsed'], 'unit': 'images/s',
            'ms_per_step': 1000.0 * r['elapsed'] / steps, 'steps': steps, 'warmup': warmup,
            'launch_mode': r['launch_mode'],
+           **({'ms_per_step_median': r['step_ms_median'], 'ms_per_step_min_max': r['step_ms_min_max']}
+              if r.get('step_ms_median') else {}),
            'config': {'workload': f'{wl["desc"]}, batch={batch_per_gpu}/GPU, {run.sample_steps} sampling steps ({wl["ref"]})',
                       'global_batch': batch_per_gpu * world},
            'stages': stage_view(r['stage_ms'], batch_per_gpu, run.sample_steps, run.upscale, r['stats'])}
@@ -594,6 +618,116 @@ def side_config(name, run, steps, warmup, batch_per_gpu, world, dworld, dev, pro
             out['roofline'] = gemm_roofline(e['prof'], name)
         out['eager_launches_ms_per_step'] = e['ms_per_step']
     return out
+
+
+
+# --------------------------------------------------------------------------- the contract line
+
+
+DTYPE_SPLIT = '2xf16-split operands (22 significant bits), f32 accumulate; exact-f32 number: exact_fp32_path'
+COMPACT_LIMIT = 6000  # bytes; the driver keeps the last 8 KB of stdout and parses the last line
+
+
+def _r(x, nd=4):
+    """Floats to `nd` significant digits (the line is a record, not a data file); everything else unchanged."""
+    if isinstance(x, float):
+        return float(f'{x:.{nd}g}')
+    return x
+
+
+def _pick(d, keys, nd=4):
+    return {k: _r(d[k], nd) for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def compact_line(out):
+    """The ONE stdout line: the harness contract's keys and nothing wordy.  `out` is the full result dict of main()
+    (written to gpurun_out/bench_detail.json and stderr); this keeps metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / dtype / config, `roofline` and `cpu_baseline` reduced to numbers + short labels, one number per
+    side measurement, and `other_configs` as {value, ms_per_step, steps, roofline_frac}.  Always < COMPACT_LIMIT bytes
+    (tests/test_bench_line.py)."""
+    c = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+                                    'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data') if k in out}
+    c['dtype'] = str(out.get('dtype', ''))[:120]
+    cfg = out.get('config', {})
+    c['config'] = {'workload': str(cfg.get('workload', ''))[:200], **_pick(cfg, ('global_batch', 'sample_steps')),
+                   'parallelism': str(cfg.get('parallelism', ''))[:60]}
+    if 'ms_per_step_median' in out:
+        c['ms_per_step_median'] = _r(out['ms_per_step_median'], 6)
+    rf = out.get('roofline')
+    if rf:
+        c['roofline'] = {'bound': rf.get('bound'), 'kernel': str(rf.get('kernel', ''))[:60],
+                         **_pick(rf, ('achieved', 'peak')), 'unit': rf.get('unit'), **_pick(rf, ('frac',)),
+                         'traffic': _r(rf.get('traffic')),
+                         **_pick(rf, ('frac_useful', 'avg_launch_us', 'avg_launch_us_rocprof', 'mfma_util_pmc',
+                                      'main_loop_shader_clock_ghz', 'frac_of_peak_at_measured_clock',
+                                      'launches_sampled', 'flop_per_launch'))}
+    cb = out.get('cpu_baseline')
+    if cb:
+        c['cpu_baseline'] = {'value': _r(cb.get('value')), 'unit': cb.get('unit'), 'cores': cb.get('cores'),
+                             'kind': cb.get('kind'), 'sample': str(cb.get('sample', ''))[:240]}
+    st = out.get('stages') or {}
+    if st:
+        c['stages_ms'] = {k: _r(v['ms_per_step']) for k, v in st.items()}
+        sm, rd = st.get('sampler', {}), st.get('refine_decode', {})
+        c['sampler'] = _pick(sm, ('rounds', 'ms_per_round', 'sample_steps_evaluated', 'executed_frac_of_16bit_peak'))
+        c['decode'] = _pick(rd, ('ms_per_image', 'hbm_frac', 'compute_frac_of_16bit_mfma_peak'))
+    if 'exact_fp32_path' in out:
+        c['exact_fp32_path'] = _pick(out['exact_fp32_path'], ('value', 'ms_per_step'))
+    if 'parity' in out:
+        c['parity'] = _pick(out['parity'], ('tokens_equal', 'token_mismatches', 'bot_indices_equal', 'img_max_abs',
+                                            'img_u8_max_abs'))
+    if 'eager_launches' in out:
+        c['eager_launches'] = _pick(out['eager_launches'], ('value', 'tokens_equal', 'images_u8_equal',
+                                                            'host_calls_per_round'))
+    if 'eager_gpu_baseline' in out:
+        c['eager_gpu_baseline'] = _pick(out['eager_gpu_baseline'], ('sampler_ms_per_step',
+                                                                    'this_package_sampler_ms_per_step', 'speedup'))
+    if out.get('launch_mode'):
+        c['launch_mode'] = str(out['launch_mode']).split(':')[0][:40]
+    for k in ('host_launches_per_round', 'rccl_world', 'dist_backend', 'path_tflops'):
+        if out.get(k) is not None:
+            c[k] = _r(out[k])
+    for k in ('per_rank_ms_per_step', 'per_rank_image_checksum'):
+        if out.get(k) is not None:
+            c[k] = [_r(v, 10 if 'checksum' in k else 6) for v in out[k]]
+    oc = out.get('other_configs')
+    if oc:
+        c['other_configs'] = {}
+        for name, leg in oc.items():
+            e = _pick(leg, ('value', 'ms_per_step', 'ms_per_step_median', 'steps'))
+            e['global_batch'] = leg.get('config', {}).get('global_batch')
+            if leg.get('launch_mode'):
+                e['launch_mode'] = leg['launch_mode']
+            if leg.get('roofline'):
+                e['roofline_frac'] = _r(leg['roofline'].get('frac'))
+            lst = leg.get('stages') or {}
+            if 'refine_decode' in lst:
+                e['decode_ms_per_image'] = _r(lst['refine_decode'].get('ms_per_image'))
+            c['other_configs'][name] = e
+    if out.get('detail'):
+        c['detail'] = out['detail']
+    line = json.dumps(c, separators=(',', ':'))
+    if len(line) >= COMPACT_LIMIT:  # cannot happen with the fields above; never let the contract line grow again
+        for k in ('per_rank_image_checksum', 'per_rank_ms_per_step', 'stages_ms', 'eager_launches', 'sampler', 'decode'):
+            c.pop(k, None)
+        line = json.dumps(c, separators=(',', ':'))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(out):
+    """Full result -> gpurun_out/bench_detail.json (+ stderr); the compact contract line -> stdout (the LAST line)."""
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        name = 'bench_detail.json' if out.get('n_gpus', 1) == 1 else f'bench_detail_n{out["n_gpus"]}.json'
+        with open(os.path.join(d, name), 'w') as f:
+            json.dump(out, f, indent=1)
+        out['detail'] = f'gpurun_out/{name}'
+    except OSError:
+        pass
+    print('bench detail: ' + json.dumps(out), file=sys.stderr, flush=True)
+    print(compact_line(out), flush=True)
 
 
 # --------------------------------------------------------------------------- main
@@ -670,7 +804,7 @@ def main(argv=None):
     # timed region, no collective: every rank runs it on its own)
     eager = None
     if not stub and not args.no_eager_leg:
-        eager = run.eager_profile(max(1, args.other_steps))
+        eager = run.eager_profile(max(1, args.eager_steps))
     # a checksum of every rank's images reaches rank 0 (the optional image gather of SURVEY 8(e))
     sums = shard.gather_floats(float(u8.to(torch.float64).sum()), dworld, dev)
 
@@ -715,15 +849,16 @@ def main(argv=None):
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': 1000.0 * elapsed / args.steps,
+        **({'ms_per_step_median': res['step_ms_median'], 'ms_per_step_min_max': res['step_ms_min_max']}
+           if res.get('step_ms_median') else {}),
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': ('stub' if stub else 'f32' if not split_on else
-                  '2xf16-split operands (22 significant bits), f32 accumulate: sampler Linears + attention and the '
-                  'decoder convolutions as 3 fp16 partial products per multiply on v_mfma_f32_32x32x16_f16 -- '
-                  'fp32-class accuracy, see "parity" and "exact_fp32_path" for the strictly-fp32 number; '
-                  'tokenizer, index-prediction UNet, parsing generator exact-f32 MFMA; GELU by a 3-ulp rational erf, '
-                  'softmax in the base-2 domain'),
+        'dtype': ('stub' if stub else 'f32' if not split_on else DTYPE_SPLIT),
+        'dtype_detail': ('sampler Linears + attention and the decoder convolutions as 3 fp16 partial products per multiply '
+                         'on v_mfma_f32_32x32x16_f16 -- fp32-class accuracy, see "parity" and "exact_fp32_path" for the '
+                         'strictly-fp32 number; tokenizer, index-prediction UNet, parsing generator exact-f32 MFMA; GELU '
+                         'by a 3-ulp rational erf, softmax in the base-2 domain'),
         'data': 'synthetic',
         'config': {
             'workload': (f'{wl["desc"]}, batch={batch_per_gpu}/GPU, {args.sample_steps} sampling steps '
@@ -744,7 +879,7 @@ def main(argv=None):
     if stub:
         if other:
             out['other_configs'] = other
-        print(json.dumps(out), flush=True)
+        emit(out)
         dist and dist.destroy_process_group()
         return
 
@@ -765,7 +900,7 @@ def main(argv=None):
             'images_u8_equal': bool(torch.equal(eager['u8'], u8)),
             'host_calls_per_step': eager['host_calls_per_step'],
             'host_calls_per_round': eager['host_calls_per_step'] / rounds,
-            'note': f'T2H_GRAPH=0 with the GEMM event sampling armed, 1 warm-up + {max(1, args.other_steps)} steps; the headline '
+            'note': f'T2H_GRAPH=0 with the GEMM event sampling armed, 1 warm-up + {max(1, args.eager_steps)} steps; the headline '
                     'issues 1 graph launch per round instead'}
         out['host_launches_per_round'] = 1 if res['launch_mode'] == 'graph' else eager['host_calls_per_step'] / rounds
     # ---- stage view (HIP events on the launch stream), incl. decode's compute AND HBM fractions
@@ -823,7 +958,7 @@ def main(argv=None):
         }
     if world == 1 and args.eager_gpu_baseline:
         out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, 16, dev)
-    print(json.dumps(out), flush=True)
+    emit(out)
     if use_dist:
         dist.destroy_process_group()
 

@@ -29,6 +29,9 @@ def _run(nproc, extra=()):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, f'stdout must hold exactly one JSON line, got: {lines}'
+    # the harness keeps the last 8 KB of stdout: the contract line stays far below (a 26.5 KB line was lost)
+    assert len(lines[0]) < 6000, len(lines[0])
+    assert 'bench detail: {' in r.stderr  # the full result goes to stderr + gpurun_out/bench_detail*.json
     return json.loads(lines[0])
 
 
@@ -47,9 +50,10 @@ def test_bench_two_ranks_gloo():
     assert len(cs) == 2 and cs[0] != cs[1]
     # the configs[3] leg ran on both ranks too (its barrier / max-over-ranks collectives are the headline's)
     leg = out['other_configs']['parsing_b32']
-    assert leg['config']['global_batch'] == 2 * 2 * 3 and leg['value'] > 0 and leg['steps'] == 2
+    assert leg['global_batch'] == 2 * 2 * 3 and leg['value'] > 0 and leg['steps'] == 5
     # the stub walks the graph-replay host logic (schedule.RoundTables) on every rank's own shard
-    assert leg['launch_mode'] == 'graph' and leg['stages'] == {}
+    assert leg['launch_mode'] == 'graph'
+    assert out['detail'] == 'gpurun_out/bench_detail_n2.json'
     # the shards are those of the single-process run over the same global batch
     one = _run(1, ('--batch', '6'))
     assert one['rccl_world'] == 1 and len(one['per_rank_image_checksum']) == 1
