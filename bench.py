@@ -99,8 +99,9 @@ def parse_args(argv=None):
                          'that the roofline object comes from')
     ap.add_argument('--other-steps', type=int, default=5, help='timed steps of each other_configs leg (after 1 warm-up)')
     ap.add_argument('--eager-steps', type=int, default=2, help='steps of the individual-launches leg (after 1 warm-up)')
-    ap.add_argument('--eager-gpu-baseline', action='store_true',
-                    help='also time the oracle sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
+    ap.add_argument('--no-eager-gpu-baseline', action='store_true',
+                    help='skip the reference sampler as eager PyTorch-ROCm ops on this GPU (SURVEY.md 8(d))')
+    ap.add_argument('--eager-gpu-steps', type=int, default=8)
     ap.add_argument('--stub-model', action='store_true',
                     help='TEST ONLY (tests/test_bench_dist.py): CPU + gloo + a stub model, to exercise the '
                          'multi-rank shard / seed / timing / gather logic of this file without a GPU')
@@ -111,15 +112,48 @@ def parse_args(argv=None):
 
 
 def cpu_baseline_worker(sample_steps, n_sub, threads, repeats):
-    """Times the oracle (oracle/torch_ref.py = CPU port of the reference path) on a bounded
-    sample: B=1, tokenizer + n_sub sampler steps (scaled to `sample_steps`) + refine + decode,
-    `repeats` times, median.  Runs in its own process (see below)."""
-    from oracle import torch_ref as R
+    """Runs in its own process (no GPU context, own OpenMP pool; see cpu_baseline()).  B=1, seed 2021, `threads`
+    host threads.
+
+    kind "reference": the UNMODIFIED reference `SampleFromParsingModel` (models/sample_model.py:215-328) through
+    oracle/ref_shim.py -- from oracle/_ref's byte code on the GPU box (oracle/make_ref.py), from /root/reference in
+    the build container -- on the reference's own call sequence `feed_data` + `sample_and_refine` (what
+    `inference` runs per batch, sample_model.py:355-359), ALL `sample_steps` sampling steps, once, after a 2-step
+    warm-up of the same call.
+    kind "port": only where the reference is not available: oracle/torch_ref.py on a bounded sample (tokenizer +
+    n_sub sampler steps scaled to `sample_steps` + refine + decode, median of `repeats`)."""
+    import contextlib
+    import io
+    import tempfile
+    from oracle import ref_shim, torch_ref as R
     from text2human_amd import defaults, options, synthetic
     torch.set_num_threads(threads)
     opt = options.dict_to_nonedict(defaults.sample_from_parsing())
-    sds = synthetic.make_state_dicts(opt, seed=1234)
     batch = synthetic.parsing_batch(1, seed=2021)
+    if ref_shim.available() and os.environ.get('T2H_CPU_BASELINE') != 'port':
+        ns = ref_shim.load_reference('cpu')
+        with tempfile.TemporaryDirectory() as d:
+            o = synthetic.write_checkpoints(opt, d, seed=1234)
+            with contextlib.redirect_stdout(io.StringIO()):
+                model = ns.sample_model.SampleFromParsingModel(o)
+        with torch.no_grad():
+            model.sample_steps = 2
+            model.feed_data(batch)
+            model.sample_and_refine('/nonexistent', batch['img_name'])  # warm-up (the shim captures save_image)
+            model.sample_steps = sample_steps
+            ns.util.set_random_seed(2021)
+            t0 = time.perf_counter()
+            model.feed_data(batch)
+            t1 = time.perf_counter()
+            model.sample_and_refine('/nonexistent', batch['img_name'])
+            t2 = time.perf_counter()
+        img = ref_shim.saved_images[-1][0]
+        per_image = t2 - t0
+        return dict(value=1.0 / per_image, unit='images/s', cores=torch.get_num_threads(), kind='reference',
+                    sample=(f'unmodified reference ({ref_shim.kind()}) SampleFromParsingModel, B=1, seed 2021: feed_data '
+                            f'{t1 - t0:.2f}s + sample_and_refine (all {sample_steps} steps + refine + decode) {t2 - t1:.1f}s '
+                            f'= {per_image:.1f} s/image, one run after a 2-step warm-up; image mean {float(img.mean()):.4f}'))
+    sds = synthetic.make_state_dicts(opt, seed=1234)
     runs = []
     with torch.no_grad():
         R.transformer_logits(torch.zeros(1, 512, dtype=torch.long), torch.zeros(1, 512, dtype=torch.long),
@@ -139,10 +173,10 @@ def cpu_baseline_worker(sample_steps, n_sub, threads, repeats):
     runs.sort()
     per_image, tk, sm, dc = runs[len(runs) // 2]
     return dict(value=1.0 / per_image, unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample=(f'median of {repeats}: B=1, tokenizer {tk:.2f}s + {n_sub} of {sample_steps} sampler steps '
+                sample=(f'reference byte code (oracle/_ref) absent: the PORT oracle/torch_ref.py, median of {repeats}: B=1, '
+                        f'tokenizer {tk:.2f}s + {n_sub} of {sample_steps} sampler steps '
                         f'{sm:.2f}s (scaled x{sample_steps / n_sub:g}) + refine/decode {dc:.2f}s'
-                        f' -> {per_image:.1f} s/image; all runs s/image: '
-                        + ', '.join(f'{r[0]:.1f}' for r in runs)))
+                        f' -> {per_image:.1f} s/image'))
 
 
 def cpu_baseline(sample_steps, n_sub, repeats):
@@ -156,18 +190,26 @@ def cpu_baseline(sample_steps, n_sub, repeats):
            '--cpu-repeats', str(repeats)]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
                HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
-        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
-        if line:
-            out = json.loads(line[-1])
-            out['calibration'] = reference_calibration()
-            return out
-        return dict(value=None, unit='images/s', cores=threads, kind='port',
-                    sample=f'worker failed: {r.stderr[-300:]}')
-    except subprocess.TimeoutExpired:
-        return dict(value=None, unit='images/s', cores=threads, kind='port',
-                    sample='worker exceeded its 300 s time box')
+    fail = None
+    for attempt in ('reference', 'port'):
+        if attempt == 'port':
+            env['T2H_CPU_BASELINE'] = 'port'  # the reference leg failed or ran out of its box: the bounded port
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300 if attempt == 'reference' else 200,
+                               env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if line:
+                out = json.loads(line[-1])
+                if fail:
+                    out['sample'] = f'({fail}) ' + out['sample']
+                out['calibration'] = reference_calibration()
+                return out
+            fail = f'{attempt} worker failed: {r.stderr[-200:]}'
+        except subprocess.TimeoutExpired:
+            fail = f'{attempt} worker exceeded its time box'
+        if env.get('T2H_CPU_BASELINE') == 'port':
+            break
+    return dict(value=None, unit='images/s', cores=threads, kind='port', sample=fail)
 
 
 def reference_calibration():
@@ -190,12 +232,16 @@ def reference_calibration():
             'tokens_equal': d['tokens_equal'], 'image_max_abs': d['image_max_abs']}
 
 
-def eager_gpu_baseline(model, batch, sds, n_sub, dev):
-    """The un-tuned GPU baseline of SURVEY.md 8(d): the oracle's sampler (the reference's
-    algorithm as eager PyTorch-ROCm fp32 ops) on this same GPU and batch."""
-    from oracle import torch_ref as R
-    sd = {k: v.to(dev) for k, v in sds['sampler'].items()}
-    tok = model.segm_tokens.view(model.batch_size, -1)
+def eager_gpu_baseline(model, batch, sds, opt, n_sub, dev):
+    """The un-tuned GPU baseline of SURVEY.md 8(d): the reference's sampler as eager PyTorch-ROCm fp32 ops on this
+    same GPU and batch -- the UNMODIFIED reference model (`sample_fn`, models/sample_model.py:256-328, through
+    oracle/ref_shim.py: oracle/_ref's byte code on the GPU box) where it is available, else the oracle port."""
+    import contextlib
+    import io
+    import tempfile
+    from oracle import ref_shim, torch_ref as R
+    from text2human_amd import options, synthetic
+    B = model.batch_size
 
     def timed(fn):
         fn(2)
@@ -205,12 +251,39 @@ def eager_gpu_baseline(model, batch, sds, n_sub, dev):
         torch.cuda.synchronize()
         return 1000.0 * (time.perf_counter() - t0) / n_sub
 
-    with torch.no_grad():
-        eager = timed(lambda n: R.sample_fn(tok, model.texture_mask, sd, sample_steps=n, noise=R.TorchNoise(dev)))
+    kind = None
+    ns = None
+    if ref_shim.available():
+        try:
+            ns = ref_shim.load_reference(dev)
+        except Exception:  # noqa: BLE001 -- a baseline leg never takes the bench down
+            ns = None
+    if ns is not None:
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                o = synthetic.write_checkpoints(opt, d, seed=1234)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ref = ns.sample_model.SampleFromParsingModel(o)
+            with torch.no_grad():
+                ref.feed_data({k: batch[k] for k in ('segm', 'texture_mask', 'img_name')})
+                options.set_random_seed(2021)
+                eager = timed(lambda n: ref.sample_fn(temp=1, sample_steps=n))
+            kind = f'unmodified reference sample_fn ({ref_shim.kind()}) as eager PyTorch-ROCm fp32 on the same GPU'
+            del ref
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            kind = None
+            print(f'eager_gpu_baseline: reference leg failed ({type(e).__name__}: {e})', file=sys.stderr)
+    if kind is None:
+        sd = {k: v.to(dev) for k, v in sds['sampler'].items()}
+        tok = model.segm_tokens.view(B, -1)
+        with torch.no_grad():
+            eager = timed(lambda n: R.sample_fn(tok, model.texture_mask, sd, sample_steps=n, noise=R.TorchNoise(dev)))
+        kind = 'oracle port sample_fn as eager PyTorch-ROCm fp32 on the same GPU'
+    options.set_random_seed(2021)
     ours = timed(lambda n: model.sample_fn(temp=1, sample_steps=n))
-    return dict(kind='oracle sampler as eager PyTorch-ROCm fp32 on the same GPU', sampler_ms_per_step=eager,
-                this_package_sampler_ms_per_step=ours, speedup=eager / ours,
-                sample=f'B={tok.shape[0]}, {n_sub} sampler steps each (the sampler is 97% of the path)')
+    return dict(kind=kind, sampler_ms_per_step=eager, this_package_sampler_ms_per_step=ours, speedup=eager / ours,
+                sample=f'B={B}, {n_sub} sampler steps each after 2 warm-up steps (the sampler is 97% of the path)')
 
 
 # --------------------------------------------------------------------------- profile side data
@@ -680,8 +753,10 @@ def compact_line(out):
         c['eager_launches'] = _pick(out['eager_launches'], ('value', 'tokens_equal', 'images_u8_equal',
                                                             'host_calls_per_round'))
     if 'eager_gpu_baseline' in out:
-        c['eager_gpu_baseline'] = _pick(out['eager_gpu_baseline'], ('sampler_ms_per_step',
-                                                                    'this_package_sampler_ms_per_step', 'speedup'))
+        c['eager_gpu_baseline'] = {'kind': ('reference' if 'unmodified reference' in str(out['eager_gpu_baseline'].get('kind'))
+                                            else 'port'),
+                                   **_pick(out['eager_gpu_baseline'], ('sampler_ms_per_step',
+                                                                       'this_package_sampler_ms_per_step', 'speedup'))}
     if out.get('launch_mode'):
         c['launch_mode'] = str(out['launch_mode']).split(':')[0][:40]
     for k in ('host_launches_per_round', 'rccl_world', 'dist_backend', 'path_tflops'):
@@ -956,8 +1031,8 @@ def main(argv=None):
             'images_u8_equal': bool(int(diff.max()) == 0), 'img_u8_max_abs': int(diff.max()),
             'img_u8_frac_differing': float((diff != 0).float().mean()),
         }
-    if world == 1 and args.eager_gpu_baseline:
-        out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, 16, dev)
+    if world == 1 and not args.no_eager_gpu_baseline and args.config != 'pose':
+        out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, opt, args.eager_gpu_steps, dev)
     emit(out)
     if use_dist:
         dist.destroy_process_group()

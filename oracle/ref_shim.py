@@ -1,10 +1,13 @@
 """TEST INFRASTRUCTURE ONLY -- never imported by the product path.
 
-Loads the *unmodified* reference (yumingj/Text2Human) from ``/root/reference``
-so that (a) the CPU restatement in ``oracle/torch_ref.py`` can be validated
-against it and (b) ``oracle/make_golden.py`` can emit golden vectors.  The
-reference cannot travel to the GPU box, so nothing under ``tests/ -m gpu``,
-``bench.py`` or ``__graft_entry__.smoke()`` may import this module.
+Loads the *unmodified* reference (yumingj/Text2Human) so that (a) the CPU
+restatement in ``oracle/torch_ref.py`` can be validated against it, (b)
+``oracle/make_golden.py`` can emit golden vectors and (c) ``bench.py``'s
+``cpu_baseline`` times the reference itself.  From ``/root/reference`` (the
+sources, build container) or, where that does not exist (the GPU box), from the
+byte code ``oracle/make_ref.py`` compiled from those sources into the git-ignored
+``oracle/_ref/`` -- the same modules, no source copied.  Nothing at run time reads
+``/root/reference`` on the GPU box.
 
 The reference hard-imports packages that are absent offline (mmcv, mmseg,
 torchvision, lpips) and hard-codes ``torch.device('cuda')``
@@ -20,6 +23,7 @@ The stubs below restate only the pieces the sampling path touches:
 * ``torchvision.utils.save_image`` captures the tensor instead of writing PNG.
 """
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -28,13 +32,47 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-REFERENCE_ROOT = os.environ.get('T2H_REFERENCE_ROOT', '/root/reference')
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BYTECODE_ROOT = os.path.join(_HERE, '_ref')  # oracle/make_ref.py: byte code compiled from /root/reference
+
+
+def _bytecode_ok(root):
+    """oracle/_ref holds byte code of THIS interpreter (same image in the build container and on the GPU box)."""
+    import json
+    try:
+        m = json.load(open(os.path.join(root, 'MANIFEST.json')))
+    except (OSError, ValueError):
+        return False
+    return (m.get('magic') == importlib.util.MAGIC_NUMBER.hex()
+            and os.path.exists(os.path.join(root, 'models', 'sample_model.pyc')))
+
+
+def _pick_root():
+    env = os.environ.get('T2H_REFERENCE_ROOT')
+    if env:
+        return env
+    if os.path.isdir('/root/reference/models/archs'):
+        return '/root/reference'
+    return BYTECODE_ROOT
+
+
+REFERENCE_ROOT = _pick_root()
 
 saved_images = []  # (tensor, path) captured from the save_image stub
 
 
+def kind():
+    """'source' (the reference tree itself, build container), 'bytecode' (oracle/_ref, anywhere) or None."""
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, 'models', 'archs')):
+        if os.path.exists(os.path.join(REFERENCE_ROOT, 'models', 'sample_model.py')):
+            return 'source'
+        if _bytecode_ok(REFERENCE_ROOT):
+            return 'bytecode'
+    return None
+
+
 def available():
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, 'models', 'archs'))
+    return kind() is not None
 
 
 class _Registry:

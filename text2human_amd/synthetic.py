@@ -464,12 +464,12 @@ def make_state_dicts(opt, seed=1234, head_scale=1.0, argmax_scale=1.0, encode=Fa
     return sds
 
 
-def write_checkpoints(opt, out_dir, seed=1234, **kw):
+def write_checkpoints(opt, out_dir, seed=1234, state_dicts=None, **kw):
     """Writes the 5 (+1 for pose) `.pth` files in the reference layout
     (SURVEY.md section 5 "Checkpoint / resume") and returns an opt copy whose
-    *_path keys point at them."""
+    *_path keys point at them.  `state_dicts`: write these instead of make_state_dicts(opt, seed, **kw)."""
     os.makedirs(out_dir, exist_ok=True)
-    sds = make_state_dicts(opt, seed, **kw)
+    sds = state_dicts if state_dicts is not None else make_state_dicts(opt, seed, **kw)
     files = {
         'top_vae_path': ('vqvae_top.pth', dict(decoder=sds['decoder'],
                                                quantize=sds['top_quantize'],
