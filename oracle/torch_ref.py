@@ -252,6 +252,14 @@ def spatial_texture_vq_forward(z, texture_mask, books_sd, spatial=2):
     return zq, idx_lists
 
 
+def encode_latents(image, sds):
+    """The tensors the two texture-aware quantizers see (hierarchy_inference_model.py:171-172,188-189):
+    (top f32 [B,256,32,16], bottom f32 [B,256,64,32]) = Encoder -> 1x1 quant_conv of each level."""
+    zt = F.conv2d(encoder(image, sds['top_encoder']), sds['top_quant_conv']['weight'], sds['top_quant_conv']['bias'])
+    zb = F.conv2d(encoder(image, sds['bot_encoder']), sds['bot_quant_conv']['weight'], sds['bot_quant_conv']['bias'])
+    return zt, zb
+
+
 def top_encode(image, texture_mask, sds):
     """top_encode, hierarchy_inference_model.py:170-176: Encoder -> 1x1 quant_conv ->
     texture-routed VQ -> 1x1 post_quant_conv.  Returns (quant_t [B,256,32,16], idx lists)."""

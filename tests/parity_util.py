@@ -30,16 +30,16 @@ def seed_all(s):
     torch.cuda.manual_seed_all(s)
 
 
-def oracle_run(segm_tokens, texture_mask, sd_dev, steps, seed):
+def oracle_run(segm_tokens, texture_mask, sd_dev, steps, seed, temp=1.0):
     """-> (list of 18 token tensors, {t: trace dict}, {t: generator state at the start of step t})"""
     noise, trace = RecordingNoise(DEV), []
     seed_all(seed)
     with torch.no_grad():
-        ref = R.sample_fn(segm_tokens, texture_mask.to(DEV), sd_dev, sample_steps=steps, noise=noise, trace=trace)
+        ref = R.sample_fn(segm_tokens, texture_mask.to(DEV), sd_dev, sample_steps=steps, temp=temp, noise=noise, trace=trace)
     return ref, {d['t']: d for d in trace}, noise.state
 
 
-def forced_run(model, trace, steps, seed, compact=True):
+def forced_run(model, trace, steps, seed, compact=True, temp=1.0):
     """HIP sampler on the oracle's trajectory; -> (list of (t, row, ours, oracle's), schedule stats).
 
     compact=False: one round per step, all samples at that step (the reference's loop).
@@ -65,7 +65,7 @@ def forced_run(model, trace, steps, seed, compact=True):
     seed_all(seed)
     tex_tok = model._texture_tokens(model.texture_mask)
     kw = dict(round_hook=round_hook, compact=True) if compact else dict(step_hook=step_hook)
-    engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, steps, model.mask_id, **kw)
+    engine.sample_tokens(model.sampler_fn, model.segm_tokens.contiguous(), tex_tok, steps, model.mask_id, temp=temp, **kw)
     return mism, dict(model.sampler_fn.last_stats)
 
 

@@ -168,9 +168,89 @@ def test_split_overflow_is_loud():
     sds['sampler']['blocks.3.ln2.weight'] = sds['sampler']['blocks.3.ln2.weight'] * 1.0e5
     model = SampleFromParsingModel(opt, state_dicts=sds)
     model.feed_data(synthetic.parsing_batch(1, seed=3))
-    with pytest.raises(engine.SplitOverflowError, match='65504'):
-        model.sample_fn(temp=1, sample_steps=2)
+    os.environ['T2H_OVERFLOW_FALLBACK'] = '0'
+    try:
+        with pytest.raises(engine.SplitOverflowError, match='65504'):
+            model.sample_fn(temp=1, sample_steps=2)
+    finally:
+        os.environ.pop('T2H_OVERFLOW_FALLBACK')
     assert not ops.split_overflow(reset=True)  # the check consumed the flag
+
+
+def test_split_overflow_falls_back_to_exact_fp32_with_the_reference_tokens():
+    """Default behaviour on a checkpoint whose activations leave fp16's range: the call is re-run on the exact-fp32
+    kernels from the generator state it started with, so the tokens (and the generator afterwards) are the ones the
+    fp32 reference gives (transformer_arch.py:91-99 computes any checkpoint) -- here against the oracle as eager
+    PyTorch-ROCm on the same generator.  The split path's captured graphs are not touched."""
+    from text2human_amd import ops
+    opt = options.dict_to_nonedict(defaults.sample_from_parsing())
+    sds = synthetic.make_state_dicts(opt, seed=1234)
+    sds['sampler']['blocks.3.ln2.weight'] = sds['sampler']['blocks.3.ln2.weight'] * 1.0e5
+    # (keep the residual stream finite: the block's MLP output is scaled back down)
+    sds['sampler']['blocks.3.mlp.0.weight'] = sds['sampler']['blocks.3.mlp.0.weight'] * 1.0e-5
+    model = SampleFromParsingModel(opt, state_dicts=sds)
+    batch = synthetic.parsing_batch(2, seed=3)
+    model.feed_data(batch)
+    sd_dev = {k: v.to(DEV) for k, v in sds['sampler'].items()}
+    steps = 12
+    seed_all(77)
+    with torch.no_grad():
+        ref = R.sample_fn(model.segm_tokens, batch['texture_mask'].to(DEV), sd_dev, sample_steps=steps,
+                          noise=R.TorchNoise(DEV))
+    ref_state = torch.cuda.get_rng_state(DEV)
+    seed_all(77)
+    with pytest.warns(UserWarning, match='exact-fp32'):
+        from text2human_amd.models import sample_model as SM
+        SM._warned.discard('index sampler')
+        top = model.sample_fn(temp=1, sample_steps=steps)
+    assert torch.equal(torch.stack(top), torch.stack(ref))
+    assert torch.equal(torch.cuda.get_rng_state(DEV), ref_state)
+    assert not ops.split_overflow(reset=True)
+    assert model.sampler_fn.split and model._sampler_exact is not None and not model._sampler_exact.split
+    # and the decode stage: a decoder whose activations overflow the split rows re-runs on the fp32 convolutions
+    sds2 = synthetic.make_state_dicts(opt, seed=1234)
+    sds2['decoder']['mid.block_1.norm2.weight'] = sds2['decoder']['mid.block_1.norm2.weight'] * 3.0e5
+    sds2['decoder']['mid.block_1.conv2.weight'] = sds2['decoder']['mid.block_1.conv2.weight'] * (1.0 / 3.0e5)
+    m2 = SampleFromParsingModel(opt, state_dicts=sds2)
+    m2.feed_data(batch)
+    seed_all(5)
+    top2 = m2.sample_fn(temp=1, sample_steps=3)
+    SM._warned.discard('VQGAN refine / decode')
+    with pytest.warns(UserWarning, match='exact-fp32'):
+        img, _ = m2.decode_indices(top2)
+    with torch.no_grad():
+        want, _ = R.refine_and_decode([t.cpu() for t in top2], batch['texture_mask'], sds2)
+    assert (img.cpu() - want).abs().max().item() < 2e-4
+    assert m2.decoder.use_split and m2.bot_decoder_res.use_split  # the next call starts on the split path again
+
+
+@pytest.mark.parametrize('temp', [0.7, 1.3])
+def test_sampling_at_a_temperature_other_than_one(temp):
+    """`logits / temp` before the categorical draw (models/sample_model.py:300-306; the UI passes other values): the
+    HIP sampler teacher-forced on the oracle's trajectory at this temperature, both schedules, the peaked-logits
+    weights (x50: a wrong temperature moves decisions there, with default weights the noise decides nearly
+    everything), and the free-running tokens.  B=4, 96 steps, device generator."""
+    Bt, steps = 4, 96
+    opt = options.dict_to_nonedict(defaults.sample_from_parsing())
+    sds = synthetic.make_state_dicts(opt, seed=1234, head_scale=50.0)
+    sd_dev = {k: v.to(DEV) for k, v in sds['sampler'].items()}
+    batch = synthetic.parsing_batch(Bt, seed=11)
+    model = SampleFromParsingModel(opt, state_dicts=sds)
+    model.feed_data(batch)
+    ref, trace, _ = oracle_run(model.segm_tokens, batch['texture_mask'], sd_dev, steps, SEED, temp=temp)
+    ref_state = torch.cuda.get_rng_state(DEV)
+    ref_t = torch.stack(ref)
+    # the temperature matters on this fixture: the same seed at temp 1 gives other tokens
+    ref1, _, _ = oracle_run(model.segm_tokens, batch['texture_mask'], sd_dev, steps, SEED, temp=1.0)
+    assert (torch.stack(ref1) != ref_t).float().mean().item() > 0.02
+    for compact in (True, False):
+        mism, _ = forced_run(model, trace, steps, SEED, compact, temp=temp)
+        assert len(mism) <= 2, (compact, mism[:5])   # (a float near-tie at most; a wrong temperature gives hundreds)
+    seed_all(SEED)
+    top = model.sample_fn(temp=temp, sample_steps=steps)
+    diff = int((torch.stack(top) != ref_t).sum())
+    assert torch.equal(torch.cuda.get_rng_state(DEV), ref_state)
+    assert diff == 0, f'{diff} of {Bt * 512} free-running tokens differ at temp {temp}'
 
 
 def test_bad_texture_id_is_rejected():

@@ -56,7 +56,7 @@ template <int C>
 __device__ __forceinline__ void sample_row(float* lds, int row, const float* __restrict__ hidden,
                                            const float* __restrict__ g, const float* __restrict__ bta,
                                            const float* __restrict__ w, const float* __restrict__ expo, int head,
-                                           float inv_temp, int64_t* __restrict__ x_t,
+                                           float temp, int64_t* __restrict__ x_t,
                                            int64_t* __restrict__ out_idx, int n_class) {
   constexpr int VPL = C / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void sample_row(float* lds, int row, const float* __r
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float r = wave_sum(acc[u]);
-      if (lane == 0 && j0 + u < n_class) lds[j0 + u] = r * inv_temp;
+      if (lane == 0 && j0 + u < n_class) lds[j0 + u] = r / temp;  // (the reference divides: logits / temp, sample_model.py:303)
     }
   }
   __syncthreads();
@@ -164,12 +164,12 @@ template <int C>
 __global__ __launch_bounds__(SH_THREADS) void sample_head_kernel(
     const float* __restrict__ hidden, const float* __restrict__ g, const float* __restrict__ bta,
     const float* __restrict__ w, const float* __restrict__ expo, const uint8_t* __restrict__ changes,
-    const int64_t* __restrict__ tex, int head, float inv_temp, int64_t* __restrict__ x_t,
+    const int64_t* __restrict__ tex, int head, float temp, int64_t* __restrict__ x_t,
     int64_t* __restrict__ out_idx, int n_class) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // n_class logits + 2*NW reduce slots
   const int row = blockIdx.x;
   if (!changes[row] || (int)tex[row] != head) return;
-  sample_row<C>(lds, row, hidden, g, bta, w, expo, head, inv_temp, x_t, out_idx, n_class);
+  sample_row<C>(lds, row, hidden, g, bta, w, expo, head, temp, x_t, out_idx, n_class);
 }
 
 // ---- sampler training-time forward (models/transformer_model.py:212-274, forward only)
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(SL_THREADS) void sample_logits_kernel(const t2h_sam
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
   }
-  const float inv_temp = 1.0f / a.temp;
+  const float temp = a.temp;
   const float* w = a.w_heads + (int64_t)head * a.n_class * C;
   const int per = (a.n_class + SL_SPLIT - 1) / SL_SPLIT;
   const int j_end = min(a.n_class, (part + 1) * per);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(SL_THREADS) void sample_logits_kernel(const t2h_sam
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float r = wave_sum(acc[u]);
-      if (lane == 0 && j0 + u < j_end) ws[(int64_t)slot * a.n_class + j0 + u] = r * inv_temp;
+      if (lane == 0 && j0 + u < j_end) ws[(int64_t)slot * a.n_class + j0 + u] = r / temp;  // (divides, like the reference)
     }
   }
 }
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(SH_THREADS) void sample_heads_kernel(const t2h_samp
   const float* expo = a.expo[head];
   if (expo == nullptr) return;  // cannot happen: a head with changed tokens always drew its noise
   sample_row<C>(lds, row, a.hidden, a.lnf_gamma, a.lnf_beta, a.w_heads + (int64_t)head * a.n_class * C, expo, head,
-                1.0f / a.temp, a.x_t, a.out_idx + (int64_t)head * a.n, a.n_class);  // (full hidden only)
+                a.temp, a.x_t, a.out_idx + (int64_t)head * a.n, a.n_class);  // (full hidden only)
 }
 
 }  // namespace
@@ -604,7 +604,7 @@ extern "C" int t2h_sample_head(const float* hidden, const float* lnf_gamma, cons
   const size_t lds = (size_t)(n_class + 2 * (SH_THREADS / 64)) * sizeof(float);
   hipLaunchKernelGGL(sample_head_kernel<512>, dim3(n), dim3(SH_THREADS), lds,
                      static_cast<hipStream_t>(stream), hidden, lnf_gamma, lnf_beta, w_head, expo,
-                     changes, tex, head, 1.0f / temp, x_t, out_idx, n_class);
+                     changes, tex, head, temp, x_t, out_idx, n_class);
   T2H_CHECK_LAUNCH("t2h_sample_head");
   return T2H_OK;
 }

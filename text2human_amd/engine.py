@@ -226,6 +226,7 @@ class SamplerNet:
         C = self.desc['C']
         full = buf = self._buffers(B * T, C, idx.device)
         if self.split and self.split_mha and tuple(full['vt'].shape) != (B, self.n_head, 2, C // self.n_head, T):
+            self._graphs = {}  # (captured rounds hold a pointer to the buffer replaced here)
             full['vt'] = ops.vt_empty(B, self.n_head, T, idx.device, C // self.n_head)
         if active is not None and 0 < active < B:
             k = int(active)
@@ -485,7 +486,8 @@ class RoundGraph:
     the same arguments every time: t2h_schedule_advance moves the round's rows / generator offsets from
     the run's padded tables into fixed staging buffers, the 24 layers and the sampling tail work on
     persistent buffers, the seed is read from device memory.  Captured once per (batch, padded rows per
-    round, temperature), replayed for every round of every run."""
+    round -- a power of two --, temperature) for every count of running samples, before the first run
+    (prepare), replayed for every round of every run."""
 
     def __init__(self, net, B, T, steps, maxr, n_books, n_class, temp, mask_id, dev):
         i64 = lambda *s: torch.empty(s, dtype=torch.int64, device=dev)
@@ -502,6 +504,23 @@ class RoundGraph:
         self.stream = torch.cuda.Stream(device=dev)
         self.B = B
         self.graphs = {}  # samples still running (a prefix of the batch, schedule.leave_order) -> captured round
+        self.pool = torch.cuda.graph_pool_handle()  # one memory pool for all of them (a capture allocates nothing big)
+
+    def prepare(self, counts):
+        """Captures the round for every count of running samples in `counts` (all of 1..B when finished samples
+        leave the batch), once, before the first run: which counts a run meets depends on its seed, and a capture
+        in the middle of a later run would be an eager round + a device-wide synchronisation inside the sampling
+        loop.  One eager round on a valid dummy state first (it
+        sizes every lazily allocated workspace); a capture itself executes nothing.  Call on self.stream."""
+        self.x_t.fill_(self.mask_id)
+        self.out.fill_(-1)
+        for t in (self.segm, self.tex, self.rows_tbl, self.offs_tbl, self.rng_tbl, self.round_ctr, self.seed):
+            t.zero_()
+        self.body(self.B)
+        self.stream.synchronize()
+        for k in sorted(counts, reverse=True):
+            if k not in self.graphs:
+                self.capture(k)
 
     def body(self, k):
         """One round on the first k samples of the batch (the others have no step left)."""
@@ -524,7 +543,7 @@ class RoundGraph:
         gc_was_on = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
+            with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode='thread_local'):
                 self.body(k)
         finally:
             if gc_was_on:
@@ -542,6 +561,10 @@ class RoundGraph:
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
             ops.split_overflow(reset=True)  # (this stream's flag; allocated here, before any capture)
+            counts = set(range(1, self.B + 1)) if sched.active is not None else {self.B}
+            if not counts <= set(self.graphs):
+                self.prepare(counts)
+                ops.split_overflow(reset=True)
             self.rows_tbl[:R].copy_(torch.from_numpy(rows_tbl), non_blocking=False)
             self.offs_tbl[:R].copy_(torch.from_numpy(offs_tbl), non_blocking=False)
             self.rng_tbl[:R].copy_(torch.from_numpy(tables.aux32_tbl), non_blocking=False)
@@ -553,14 +576,7 @@ class RoundGraph:
             self.seed.fill_(schedule.as_int64(sched.seed))  # (a uint64 seed >= 2^63 in its two's-complement form)
             for r in range(R):
                 k = int(active[r])
-                g = self.graphs.get(k)
-                if g is not None:
-                    g.replay()
-                else:
-                    # the first round with k running samples: eagerly (it also sizes every cached buffer), then the
-                    # capture -- which executes nothing: the device-side round cursor stands where the eager round left it
-                    self.body(k)
-                    self.capture(k)
+                self.graphs[k].replay()
             check_split_overflow('index sampler')
         caller.wait_stream(self.stream)
         return self.out
@@ -602,7 +618,10 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     # finished samples leave the batch (T2H_SHRINK_BATCH=0 opts out; hooks see the batch in its own order)
     shrink = (compact and step_hook is None and round_hook is None and os.environ.get('T2H_SHRINK_BATCH', '1') != '0')
     sched = build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact, shrink)
-    net.last_stats = schedule.stats(sched.round_steps, sample_steps, sched.active)
+    defer = bool(split and getattr(net, 'split_mha', False) and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
+    # (only the deferred-tail form of hidden() runs on the prefix of running samples; every other form evaluates the
+    # whole batch each round, and the counts say so)
+    net.last_stats = schedule.stats(sched.round_steps, sample_steps, sched.active if defer else None)
     if sched.perm is not None:
         perm_t = torch.from_numpy(sched.perm).to(dev)
         segm_tok, tex_tok = segm_tok[perm_t].contiguous(), tex_tok[perm_t].contiguous()
@@ -614,7 +633,6 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
         inv = torch.from_numpy(np.argsort(sched.perm)).to(dev)
         return out.view(out.shape[0], B, T)[:, inv].reshape(out.shape[0], n).contiguous()
 
-    defer = bool(split and getattr(net, 'split_mha', False) and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
     # Default (T2H_GRAPH=0 opts out): every round is ONE replay of a captured launch sequence (RoundGraph)
     # instead of ~180 launches from this thread.  The GPU work is the same; what changes is the host side --
     # with one process per GPU, eight Python threads issuing ~60 k launches/s each is the scaling risk of
@@ -624,7 +642,8 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     if (os.environ.get('T2H_GRAPH', '1') != '0' and defer and sched.noise_kind == 'philox' and step_hook is None
             and round_hook is None and 0 < sched.max_rows <= net.TRIM_MAX_ROWS and ops.gemm_profile_active() is False):
         net.last_launch_mode = 'graph'
-        maxr = min(net.TRIM_MAX_ROWS, -(-sched.max_rows // 16) * 16)
+        # padded rows per round: a power of two >= 16 (at most five graph sets per batch size, whatever the seeds)
+        maxr = min(net.TRIM_MAX_ROWS, max(16, 1 << (int(sched.max_rows) - 1).bit_length()))
         net._buffers(n, net.desc['C'], dev)  # (a change of batch size drops the graphs of the old buffers)
         key = (B, T, sample_steps, maxr, float(temp), int(mask_id), n_books)
         if key not in net._graphs:

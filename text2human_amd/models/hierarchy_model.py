@@ -53,11 +53,24 @@ class VQGANTextureAwareSpatialHierarchyInferenceModel():
         z, h, w = self.top_encoder.encode(self._image_rows(x), b, hh, ww)
         z = ops.gemm(z, P['top.qc.w'], bias=P['top.qc.b'])
         tex = self._tex_tokens(mask.to(self.device), h, w)
+        self._top_latent_rows = z  # [B*h*w, 256] what the codebooks see (parity tests account near-ties on it)
         self.top_indices_list = ops.vq_argmin_tex(z, P['top.books'], tex)
-        zq = ops.codebook_gather_tex(self.top_indices_list, tex, P['top.books'])
-        self._quant_t_rows = ops.gemm(zq, P['top.pq.w'], bias=P['top.pq.b'])
-        quant = ops.nhwc_to_nchw(self._quant_t_rows, b, h, w)
+        quant = self.quant_from_top_indices(self.top_indices_list, mask, (b, h, w))
         return quant, quant
+
+    @torch.no_grad()
+    def quant_from_top_indices(self, index_lists, mask, bhw):
+        """18 x i64 [B*h*w] (or [18, B*h*w]) top indices -> quant_t f32 [B, 256, h, w] (texture-routed codebook
+        lookup + top_post_quant_conv, vqgan_arch.py:289-309 + hierarchy_inference_model.py:174-175); also what
+        index_to_image decodes from.  Lets a caller continue from GIVEN top indices (tests: the reference's)."""
+        P = self.P
+        b, h, w = bhw
+        tex = self._tex_tokens(mask.to(self.device), h, w)
+        lists = index_lists if torch.is_tensor(index_lists) else torch.stack([t.reshape(-1) for t in index_lists])
+        lists = lists.reshape(lists.shape[0], -1).to(self.device, torch.long).contiguous()
+        zq = ops.codebook_gather_tex(lists, tex, P['top.books'])
+        self._quant_t_rows = ops.gemm(zq, P['top.pq.w'], bias=P['top.pq.b'])
+        return ops.nhwc_to_nchw(self._quant_t_rows, b, h, w)
 
     @torch.no_grad()
     def bot_encode(self, x, mask):
@@ -68,6 +81,7 @@ class VQGANTextureAwareSpatialHierarchyInferenceModel():
         z = ops.gemm(z, P['bot.qc.w'], bias=P['bot.qc.b'])
         ph, pw = h // self.spatial, w // self.spatial
         tex = self._tex_tokens(mask.to(self.device), ph, pw)
+        self._bot_latent_rows, self._bot_latent_hw = z, (h, w)  # NHWC rows [B*h*w, 256] before the 2x2 patch fold
         lists = ops.vq_argmin_tex(z, P['bot.books'], tex, fold_hw=(ph, pw))
         return [lists[i].view(b, ph, pw) for i in range(lists.shape[0])]
 

@@ -106,10 +106,29 @@ class BaseSampleModel():
         """models/sample_model.py:256-328 -> list of 18 int64 [B, 512]."""
         sample_steps = sample_steps or self.sample_steps
         tex_tok = self._texture_tokens(self.texture_mask)
-        out = engine.sample_tokens(self.sampler_fn, self.segm_tokens.contiguous(), tex_tok,
-                                   sample_steps, self.mask_id, temp=temp, noise=self.noise)
+        # The reference computes ANY checkpoint in fp32 (transformer_arch.py:91-99).  The split-precision kernels
+        # cover |x| < 65504; an activation outside raises SplitOverflowError at the end of the run -- after
+        # build_schedule has advanced the generator.  So: remember the generator, and on overflow restore it and
+        # run THIS call on the exact-fp32 kernels (same schedule, same draws, the reference's tokens).
+        gen = torch.cuda.default_generators[self.device.index]
+        state = gen.get_state()
+        try:
+            out = engine.sample_tokens(self.sampler_fn, self.segm_tokens.contiguous(), tex_tok,
+                                       sample_steps, self.mask_id, temp=temp, noise=self.noise)
+        except engine.SplitOverflowError as e:
+            if not _overflow_fallback('index sampler', 'T2H_SPLIT_GEMM', e):
+                raise
+            gen.set_state(state)
+            out = engine.sample_tokens(self._exact_sampler(), self.segm_tokens.contiguous(), tex_tok,
+                                       sample_steps, self.mask_id, temp=temp, noise=self.noise)
         b = self.batch_size
         return [out[i].view(b, -1) for i in range(out.shape[0])]
+
+    def _exact_sampler(self):
+        """The same transformer on the exact-fp32 matrix instructions (built on first use; shares the weights)."""
+        if getattr(self, '_sampler_exact', None) is None:
+            self._sampler_exact = engine.SamplerNet(self.P, self._tf_desc, self.opt['bert_n_head'], 'tf', split=False)
+        return self._sampler_exact
 
     # ------------------------------------------------------------ stage R
     def _top_quant_rows(self, top_lists, tex_tok):
@@ -161,6 +180,20 @@ class BaseSampleModel():
         upscale=True: 1024x512 output -- both quantised latents are nearest-x2
         upsampled before the (fully convolutional) decoders, the interpretation
         of BASELINE.json configs[4] given in SURVEY.md 8(d)."""
+        try:
+            return self._decode_indices(top_indices_list, want_u8, return_inter, upscale)
+        except engine.SplitOverflowError as e:
+            # (decode draws no random numbers: simply once more, convolutions on the exact-fp32 kernels)
+            if not _overflow_fallback('VQGAN refine / decode', 'T2H_SPLIT_CONV', e):
+                raise
+            keep = self.decoder.use_split, self.bot_decoder_res.use_split
+            self.decoder.use_split = self.bot_decoder_res.use_split = False
+            try:
+                return self._decode_indices(top_indices_list, want_u8, return_inter, upscale)
+            finally:
+                self.decoder.use_split, self.bot_decoder_res.use_split = keep
+
+    def _decode_indices(self, top_indices_list, want_u8, return_inter, upscale):
         b = self.batch_size
         tex_tok = self._texture_tokens(self.texture_mask)
         top = torch.stack([t.reshape(-1) for t in top_indices_list]).contiguous()
@@ -175,7 +208,7 @@ class BaseSampleModel():
             u8s.append(res[1])
             if return_inter:
                 inters.append(res[2])
-        if self.split_conv:  # split-precision decoder convolutions: loud on fp16-range overflow
+        if self.split_conv and self.decoder.use_split:  # split-precision convolutions: loud on fp16-range overflow
             engine.check_split_overflow('VQGAN refine / decode', knob='T2H_SPLIT_CONV')
         img = torch.cat(imgs, 0) if len(imgs) > 1 else imgs[0]
         u8 = (torch.cat(u8s, 0) if len(u8s) > 1 else u8s[0]) if want_u8 else None
@@ -206,6 +239,22 @@ class BaseSampleModel():
             img_name = data['img_name']
             self.feed_data(data)
             self.sample_and_refine(save_dir, img_name)
+
+
+_warned = set()
+
+
+def _overflow_fallback(stage, knob, err):
+    """True: re-run the stage on the exact-fp32 kernels (default; warns once per stage).  T2H_OVERFLOW_FALLBACK=0:
+    the SplitOverflowError propagates, as before."""
+    if os.environ.get('T2H_OVERFLOW_FALLBACK', '1') == '0':
+        return False
+    if stage not in _warned:
+        _warned.add(stage)
+        import warnings
+        warnings.warn(f'text2human_amd: {err}  Re-running the {stage} on the exact-fp32 kernels (about 2x slower); '
+                      f'set {knob}=0 to start there, T2H_OVERFLOW_FALLBACK=0 to raise instead.')
+    return True
 
 
 def save_u8_images(u8, save_dir, img_name):

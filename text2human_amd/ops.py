@@ -441,7 +441,8 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
             k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             k0.record()  # (creates the hipEvent_t handles the hook hands to the launch)
             k1.record()
-            stamps = torch.zeros(16 * (-(-M // 128)) * (-(-N // 64)), dtype=torch.int64, device=a_split.device)
+            # (sized for the smallest tile any configuration uses, 64 x 64: the kernel stores 16 words per workgroup unbounded)
+            stamps = torch.zeros(16 * (-(-M // 64)) * (-(-N // 64)), dtype=torch.int64, device=a_split.device)
             check(lib.t2h_gemm_split_time_next_launch(ctypes.c_void_p(k0.cuda_event), ctypes.c_void_p(k1.cuda_event)),
                   't2h_gemm_split_time_next_launch')
             check(lib.t2h_gemm_split_probe_next_launch(_p(stamps)), 't2h_gemm_split_probe_next_launch')
