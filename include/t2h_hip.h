@@ -193,6 +193,11 @@ int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, 
  * (t2h_gemm_split_args.Vt); output as fp32 rows y [B*T, C] and / or split rows y_split. */
 int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,
                       uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag, void* stream);
+/* Two forms, chosen by the number of rounds of the 256 CUs each needs: 128-query workgroups whose two wave groups
+ * take the two key halves and merge (what fills the chip at B = 8), or 256-query workgroups whose eight waves each
+ * walk all keys (B >= 16: no merge, K / Vt tiles shared by eight waves).  Tuning / tests (thread-local): 1 = all
+ * keys, 2 = key halves, 0 = automatic; returns the old value. */
+int t2h_mha_split_force_form(int form);
 
 /* ------------------------------------------------------ normalisation ------
  * LayerNorm over the last dim (eps 1e-5): transformer_arch.py:80-81,93-95,231,270 */

@@ -227,12 +227,14 @@ def test_split_overflow_falls_back_to_exact_fp32_with_the_reference_tokens():
 @pytest.mark.parametrize('temp', [0.7, 1.3])
 def test_sampling_at_a_temperature_other_than_one(temp):
     """`logits / temp` before the categorical draw (models/sample_model.py:300-306; the UI passes other values): the
-    HIP sampler teacher-forced on the oracle's trajectory at this temperature, both schedules, the peaked-logits
-    weights (x50: a wrong temperature moves decisions there, with default weights the noise decides nearly
-    everything), and the free-running tokens.  B=4, 96 steps, device generator."""
+    HIP sampler teacher-forced on the oracle's trajectory at this temperature, both schedules, and the free-running
+    tokens.  Head weights x5: calibrated with the CPU oracle so that the temperature MATTERS (a quarter of the tokens
+    differ between temp 1 and 0.7 / 1.3 under one seed; with the default weights the noise decides nearly everything,
+    with x50 the logits do) -- a kernel that ignored or mis-applied `temp` fails by hundreds of tokens.  B=4, 96 steps,
+    device generator."""
     Bt, steps = 4, 96
     opt = options.dict_to_nonedict(defaults.sample_from_parsing())
-    sds = synthetic.make_state_dicts(opt, seed=1234, head_scale=50.0)
+    sds = synthetic.make_state_dicts(opt, seed=1234, head_scale=5.0)
     sd_dev = {k: v.to(DEV) for k, v in sds['sampler'].items()}
     batch = synthetic.parsing_batch(Bt, seed=11)
     model = SampleFromParsingModel(opt, state_dicts=sds)
@@ -242,7 +244,7 @@ def test_sampling_at_a_temperature_other_than_one(temp):
     ref_t = torch.stack(ref)
     # the temperature matters on this fixture: the same seed at temp 1 gives other tokens
     ref1, _, _ = oracle_run(model.segm_tokens, batch['texture_mask'], sd_dev, steps, SEED, temp=1.0)
-    assert (torch.stack(ref1) != ref_t).float().mean().item() > 0.02
+    assert (torch.stack(ref1) != ref_t).sum().item() > 0.1 * Bt * 512
     for compact in (True, False):
         mism, _ = forced_run(model, trace, steps, SEED, compact, temp=temp)
         assert len(mism) <= 2, (compact, mism[:5])   # (a float near-tie at most; a wrong temperature gives hundreds)

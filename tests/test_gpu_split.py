@@ -121,8 +121,11 @@ def test_gemm_split_routes_value_columns_to_transposed_planes(cfg):
     assert torch.equal(vt.cpu(), _pack_vt_host(full[:, 2 * C:].contiguous(), B, T, H))
 
 
-def test_mha_split_matches_fp64_reference_as_well_as_the_fp32_kernel():
-    B, T, H, C = 2, 512, 8, 512
+@pytest.mark.parametrize('form,B', [(2, 2), (1, 2), (1, 3), (0, 16)])
+def test_mha_split_matches_fp64_reference_as_well_as_the_fp32_kernel(form, B):
+    """both forms of the kernel (t2h_mha_split_force_form: 2 = 128-query workgroups, key halves merged; 1 = 256-query
+    workgroups, every wave over all keys; 0 = the dispatcher, which takes the all-keys form at B = 16) against fp64"""
+    T, H, C = 512, 8, 512
     qkv = _rnd(B * T, 3 * C, seed=23) * 1.5
     qkv[5, C:C + 64] *= 6.0       # a spiked key: forces the online-softmax rescale
     q, k, v = [t.view(B, T, H, 64).transpose(1, 2).double() for t in qkv.split(C, dim=1)]
@@ -132,9 +135,22 @@ def test_mha_split_matches_fp64_reference_as_well_as_the_fp32_kernel():
     qk_s = ops.split_rows(qkv.to(DEV))
     vt = _pack_vt_host(qkv[:, 2 * C:].contiguous(), B, T, H).to(DEV)
     y = torch.empty(B * T, C, device=DEV)
-    ops.mha_split(qk_s, 3 * C, vt, B, T, H, out=y)
-    ys = ops.mha_split(qk_s, 3 * C, vt, B, T, H, out_split=ops.split_rows_empty(B * T, C, DEV))
+    lib = _lib.load()
+    lib.t2h_mha_split_force_form(form)
+    try:
+        ops.mha_split(qk_s, 3 * C, vt, B, T, H, out=y)
+        ys = ops.mha_split(qk_s, 3 * C, vt, B, T, H, out_split=ops.split_rows_empty(B * T, C, DEV))
+    finally:
+        lib.t2h_mha_split_force_form(0)
     assert torch.equal(ys, ops.split_rows(y))
+    if form == 0:  # B = 16: the dispatcher's choice is the all-keys form, bit for bit
+        lib.t2h_mha_split_force_form(1)
+        try:
+            y1 = torch.empty_like(y)
+            ops.mha_split(qk_s, 3 * C, vt, B, T, H, out=y1)
+        finally:
+            lib.t2h_mha_split_force_form(0)
+        assert torch.equal(y, y1)
     e32, es = (y32 - ref).abs().max().item(), (y.cpu().double() - ref).abs().max().item()
     assert es < 5e-6 + 2 * e32, f'split attention error {es:.2e} vs fp32 kernel {e32:.2e}'
 

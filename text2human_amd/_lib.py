@@ -72,6 +72,7 @@ SIGNATURES = {
     't2h_conv3x3_small_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32,
                                              c_i32, c_i32, c_vp]),
     't2h_conv_split_force_tile': (ctypes.c_int, [ctypes.c_int]),
+    't2h_mha_split_force_form': (ctypes.c_int, [ctypes.c_int]),
     't2h_split_overflow_async': (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp]),
     't2h_split_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
     't2h_layernorm_split_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp]),

@@ -269,14 +269,21 @@ constexpr int DK_TILE = KT * 256;            // K tile: 64 keys x 256 B
 constexpr int DV_TILE = 2 * HD * 128;        // Vt tile: 128 (plane, d) rows x 64 keys x 2 B
 constexpr int DKV_TILE = DK_TILE + DV_TILE;  // per key half and buffer
 
+// KH = 2 (the shape above): 4 x 32 queries x 2 key halves, merged through LDS at the end -- what fills the chip at
+// B = 8 (256 workgroups).  KH = 1: 8 x 32 queries of one (batch, head), every wave over ALL keys -- the K / Vt tiles
+// are shared by eight waves instead of four (half the L2 -> LDS bytes per query), twice the key tiles per wave behind
+// one prologue, no (m, l, O) merge and no second barrier domain.  Needs >= 256 workgroups of 256 queries to fill the
+// chip: B >= 16 (t2h_mha_split_f32 picks by the number of rounds of the 256 CUs each form takes).
+template <int KH>
 __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __restrict__ qk, int ld_cols,
                                                         const uint16_t* __restrict__ vt, float* __restrict__ y,
                                                         uint16_t* __restrict__ y_split, int T, int C, int n_head,
                                                         int* ovf) {
   // two (K, Vt) tile pairs per key half (double buffer); reused at the end for the merge + output
   // transpose staging
-  constexpr int SMEM_B = 4 * DKV_TILE > (4 * 32 * 64 + 4 * 32 * O_LD) * 4 ? 4 * DKV_TILE
-                                                                           : (4 * 32 * 64 + 4 * 32 * O_LD) * 4;
+  constexpr int NQW = 8 / KH;  // waves (x 32 queries) per key half
+  constexpr int EPI_B = KH == 2 ? (4 * 32 * 64 + 4 * 32 * O_LD) * 4 : NQW * 32 * O_LD * 4;
+  constexpr int SMEM_B = 2 * KH * DKV_TILE > EPI_B ? 2 * KH * DKV_TILE : EPI_B;
   __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_B + 16];
   float* const smem = reinterpret_cast<float*>(smem_raw);
   int* const bar = reinterpret_cast<int*>(smem_raw + SMEM_B);  // one counter per key half
@@ -291,10 +298,10 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
   if (tid < 2) bar[tid] = 0;
   __syncthreads();
   const int l31 = lane & 31, hh = lane >> 5;
-  const int qw = wave & 3, kh = wave >> 2;
+  const int qw = KH == 2 ? (wave & 3) : wave, kh = KH == 2 ? (wave >> 2) : 0;
   int qt, head, b;
   {
-    const int nqt = T / QB, total = gridDim.x, id = blockIdx.x;
+    const int nqt = T / (32 * NQW), total = gridDim.x, id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     qt = lin % nqt;
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
     head = hb % n_head;
     b = hb / n_head;
   }
-  const int q0 = qt * QB + qw * 32;
+  const int q0 = qt * (32 * NQW) + qw * 32;
   const int64_t row_b = (int64_t)(ld_cols / 32) * T2H_SPLIT_TILE_B;  // bytes per split row
   const char* const qk_b = reinterpret_cast<const char*>(qk) + (int64_t)b * T * row_b;
   const int q_tile0 = 2 * head, k_tile0 = C / 32 + 2 * head;  // 32-column tiles of this head's q / k
@@ -331,16 +338,20 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
   // the read address: K piece p of key r lives at p ^ (r & 15), Vt piece p of row r at p ^ ((r >> 1) & 7).
   // A DMA instruction fills 1 KiB lane-linearly = 4 K rows or 8 Vt rows; wave w of the half issues
   // chunks 4w .. 4w + 3 of either tile (rows 16w + 4i + (lane >> 4) / 32w + 8i + (lane >> 3)).
-  const int half_keys = T / 2;
-  const int w4 = wave & 3;
+  const int half_keys = T / KH;
+  const int w4 = qw;                 // wave inside the key half: issues CPW of the 16 1-KiB chunks of either tile
+  constexpr int CPW = 16 / NQW;      // 4 (four waves per half) or 2 (eight)
   const char* const vt_b = reinterpret_cast<const char*>(vt) + ((int64_t)(b * n_head + head) * 2 * HD) * T * 2;
   const unsigned lds_half = (unsigned)(uintptr_t)smem_raw + kh * (2 * DKV_TILE);  // this half's two buffers
   const char* const kbase = qk_b + (int64_t)(kh * half_keys) * row_b + k_tile0 * T2H_SPLIT_TILE_B;
   const char* const vbase = vt_b + (int64_t)(kh * half_keys) * 2;
-  const unsigned k_rowoff = (unsigned)(16 * w4 + (lane >> 4)) * (unsigned)row_b;
-  const unsigned k_b16 = (unsigned)((lane & 15) ^ (lane >> 4)) * 16;  // source piece of chunk i: this ^ 64 i
-  const unsigned v_rowoff = (unsigned)(32 * w4 + (lane >> 3)) * (unsigned)(T * 2);
-  const unsigned v_b16 = (unsigned)((lane & 7) ^ (lane >> 4)) * 16;   // source piece of chunk i: this ^ 64 (i & 1)
+  // (chunk c = CPW w4 + i: K rows 4 c + (lane >> 4), Vt rows 8 c + (lane >> 3))
+  const unsigned k_rowoff = (unsigned)(4 * CPW * w4 + (lane >> 4)) * (unsigned)row_b;
+  // source piece of chunk i: this ^ 64 i  (K piece p of key r lives at p ^ (r & 15), r & 15 = (4 CPW w4 & 15) + 4 i + (lane >> 4))
+  const unsigned k_b16 = (unsigned)((lane & 15) ^ (lane >> 4) ^ ((4 * CPW * w4) & 15)) * 16;
+  const unsigned v_rowoff = (unsigned)(8 * CPW * w4 + (lane >> 3)) * (unsigned)(T * 2);
+  // source piece of chunk i: this ^ 64 (i & 1)  (Vt piece p of row r at p ^ ((r >> 1) & 7) = (4 CPW w4 + 4 i + (lane >> 4)) & 7)
+  const unsigned v_b16 = (unsigned)((lane & 7) ^ (lane >> 4) ^ ((4 * CPW * w4) & 7)) * 16;
   auto dma16 = [&](unsigned voff, const char* sbase, unsigned lds_dst) {
     unsigned keep;
 #ifndef T2H_MHA_DMA_POLICY
@@ -353,15 +364,15 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
   };
   auto dma_k = [&](int it, int buf) {
     const char* const sb = kbase + (int64_t)it * KT * row_b;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_half + buf * DKV_TILE + 4 * w4 * 1024);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_half + buf * DKV_TILE + CPW * w4 * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(k_rowoff + (unsigned)(4 * i) * (unsigned)row_b + (k_b16 ^ (64u * i)), sb, dst + i * 1024);
+    for (int i = 0; i < CPW; ++i) dma16(k_rowoff + (unsigned)(4 * i) * (unsigned)row_b + (k_b16 ^ (64u * i)), sb, dst + i * 1024);
   };
   auto dma_v = [&](int it, int buf) {
     const char* const sb = vbase + it * KT * 2;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_half + buf * DKV_TILE + DK_TILE + 4 * w4 * 1024);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_half + buf * DKV_TILE + DK_TILE + CPW * w4 * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(v_rowoff + (unsigned)(8 * i) * (unsigned)(T * 2) + (v_b16 ^ (64u * (i & 1))), sb, dst + i * 1024);
+    for (int i = 0; i < CPW; ++i) dma16(v_rowoff + (unsigned)(8 * i) * (unsigned)(T * 2) + (v_b16 ^ (64u * (i & 1))), sb, dst + i * 1024);
   };
   auto dma_landed = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
 #endif
   // the second-dispatched half of the workgroup loses every issue arbitration against its older SIMD
   // partner (measured: its loop took 37k cycles against 26k): static priority evens the two out
-  if (kh == 1) __builtin_amdgcn_s_setprio(1);
+  if (KH == 2 && kh == 1) __builtin_amdgcn_s_setprio(1);
   // ---- software pipeline over the key tiles (two (K, Vt) buffers per half, one barrier per tile):
   // the matrix pipe forms S^T of tile j + 1 while the vector ALU does the softmax of tile j -- the two
   // are independent, so the compiler interleaves them instead of the wave waiting for its own matrix
@@ -416,13 +427,13 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
     dma_v(0, 0);
     if (nit > 1) dma_k(1, 1);
     dma_landed();
-    half_barrier(bar + kh, bar_n += 4, lane);
+    half_barrier(bar + kh, bar_n += NQW, lane);
     s_tile(Ks0, st, st_lo);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[ks][r] = fmaf(st_lo[ks][r], T2H_SPLIT_LO_INV, st[ks][r]);
-    half_barrier(bar + kh, bar_n += 4, lane);  // K(0) consumed by every wave before K(2) replaces it
+    half_barrier(bar + kh, bar_n += NQW, lane);  // K(0) consumed by every wave before K(2) replaces it
   }
   auto iteration = [&](int it, auto next_c) {
     constexpr bool NEXT = decltype(next_c)::value;  // also form S^T of tile it + 1 (all but the last)
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
     tm_comp += tc - tb;
     if constexpr (NEXT) {
       dma_landed();
-      half_barrier(bar + kh, bar_n += 4, lane);  // tile it + 1 published, tile it released
+      half_barrier(bar + kh, bar_n += NQW, lane);  // tile it + 1 published, tile it released
     }
     tm_stage += TM_NOW() - tc;
   };
@@ -512,12 +523,13 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[dt][r] = fmaf(o_lo[dt][r], T2H_SPLIT_LO_INV, o_acc[dt][r]);
-  // ---- merge the two key halves: waves 4-7 publish (m, l, O), waves 0-3 combine
   const long long tm2 = TM_NOW();
 #ifdef T2H_MHA_TIMING
   const long long rt2 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
   __syncthreads();
+  if constexpr (KH == 2) {
+  // ---- merge the two key halves: waves 4-7 publish (m, l, O), waves 0-3 combine
   float* const Ox = smem;                // [4 waves][32 regs][64 lanes]
   float* const Mx = smem + 4 * 32 * 64;  // borrowed from the staging area below:
   float* const Lx = Mx + 4 * 64;         // consumed before that area is written
@@ -569,6 +581,32 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
       if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
     }
   }
+  } else {
+    // ---- every wave has seen all keys: normalise, transpose its 32 x 64 tile through its own staging rows (the
+    // tile buffers are idle: the barrier above), coalesced row stores
+    const float inv_l = 1.0f / l_run;
+    float* const Os = smem + qw * 32 * O_LD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        Os[l31 * O_LD + d] = o_acc[dt][r] * inv_l;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private staging: no barrier)
+    const int64_t grow = (int64_t)b * T + q0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(Os + row * O_LD + c8 + 4);
+      if (y) {
+        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
+        *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
+      }
+      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
+    }
+  }
 #ifdef T2H_MHA_TIMING
   if (g_mha_timing && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4)) {
     long long* o = g_mha_timing + (wave == 4 ? 8 : 0);
@@ -581,7 +619,15 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
 #endif
 }
 
+thread_local int g_force_mha_form = 0;  // tuning / test hook of the calling thread: 1 all keys, 2 key halves, 0 automatic
+
 }  // namespace
+
+extern "C" int t2h_mha_split_force_form(int form) {
+  const int old = g_force_mha_form;
+  g_force_mha_form = (form == 1 || form == 2) ? form : 0;
+  return old;
+}
 
 extern "C" int t2h_mha_noncausal_f32(const float* qkv, float* y, int32_t B, int32_t T,
                                      int32_t n_head, void* stream) {
@@ -625,11 +671,22 @@ extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, cons
   T2H_REQUIRE(t2h_aligned16(qk_split) && t2h_aligned16(vt) && (!y || t2h_aligned16(y)) &&
                   (!y_split || t2h_aligned16(y_split)),
               "t2h_mha_split_f32: 16-byte alignment");
-  dim3 grid((T / QB) * n_head * B), block(512);
+  dim3 block(512);
   int* ovf = overflow_flag;
   T2H_REQUIRE(ovf != nullptr || y_split == nullptr, "t2h_mha_split_f32: overflow_flag is NULL (needed with y_split)");
-  hipLaunchKernelGGL(mha_split_pipe_kernel, grid, block, 0, static_cast<hipStream_t>(stream), qk_split, ld_cols, vt, y,
-                     y_split, T, C, n_head, ovf);
+  // Which form: rounds of the 256 CUs (one workgroup per CU at a time) x the measured length of a workgroup -- a
+  // 256-query workgroup over all keys takes 5 units where a 128-query one over the two key halves takes 3
+  // (profiles/r05_mha_all_keys.log).  B = 8: 256 x 128-query workgroups, one round; B >= 16: the all-keys form.
+  const int64_t wg2 = (int64_t)(T / QB) * n_head * B, wg1 = T % 256 == 0 ? (int64_t)(T / 256) * n_head * B : 0;
+  int form = g_force_mha_form;
+  if (form == 0) form = (wg1 > 0 && ((wg1 + 255) / 256) * 5 < ((wg2 + 255) / 256) * 3) ? 1 : 2;
+  T2H_REQUIRE(form == 2 || wg1 > 0, "t2h_mha_split_f32: the all-keys form needs T %% 256 == 0");
+  if (form == 1)
+    hipLaunchKernelGGL(mha_split_pipe_kernel<1>, dim3((unsigned)wg1), block, 0, static_cast<hipStream_t>(stream), qk_split,
+                       ld_cols, vt, y, y_split, T, C, n_head, ovf);
+  else
+    hipLaunchKernelGGL(mha_split_pipe_kernel<2>, dim3((unsigned)wg2), block, 0, static_cast<hipStream_t>(stream), qk_split,
+                       ld_cols, vt, y, y_split, T, C, n_head, ovf);
   T2H_CHECK_LAUNCH("t2h_mha_split_f32");
   return T2H_OK;
 }
