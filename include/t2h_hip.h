@@ -151,6 +151,15 @@ typedef struct t2h_gemm_split_args {
   uint16_t* Vt;
   int32_t vt_col0, vt_T, vt_hd;
   int32_t* overflow_flag; /* the caller's sticky overflow word (below); required with C_split / Vt */
+  /* "x8" operands (fmt = 1; 0 = the two-fp16-plane rows above): A and B rows are [rows][K/32][hi16: 32 fp16 | hi8:
+   * 32 e4m3 | lo8: 32 e4m3] (still 128 bytes per (row, K tile)), hi8 / lo8 = e4m3(h s), e4m3(l s) with a power of
+   * two s per tensor; the hi*hi product runs on v_mfma_f32_32x32x16_f16, BOTH cross terms of a K tile in ONE
+   * v_mfma_scale_f32_32x32x64_f8f6f4 (A = [hi8 | lo8], B = [lo8 | hi8] along its K = 64), and the cross-term
+   * accumulator is merged with lo_mul = 2^-11 / (s_A s_B) (0 = 2^-11).  out_fmt = 1 writes C_split in the x8
+   * format with scale out_scale (0 = 1); Vt planes and out_fmt = 0 outputs are unchanged.  Writers raise bit 1 of
+   * the overflow word when |x| s >= 448 (t2h_split_rows_x8_f32, t2h_layernorm_x8_f32, t2h_mha_split_f32 y_fmt 1). */
+  int32_t fmt, out_fmt;
+  float lo_mul, out_scale;
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
@@ -184,6 +193,12 @@ int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows,
  * and the attention output (transformer_arch.py:65-67) */
 int t2h_layernorm_split_f32(const float* x, const float* gamma, const float* beta, uint16_t* y_split,
                             int32_t rows, int32_t C, float eps, int32_t* overflow_flag, void* stream);
+/* the same producers for the x8 format (t2h_gemm_split_args.fmt = 1): rows [rows][C/32][hi16 | hi8 | lo8], 8-bit
+ * planes scaled by the power of two `scale` */
+int t2h_split_rows_x8_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, float scale,
+                          int32_t* overflow_flag, void* stream);
+int t2h_layernorm_x8_f32(const float* x, const float* gamma, const float* beta, uint16_t* y_x8, int32_t rows,
+                         int32_t C, float eps, float scale, int32_t* overflow_flag, void* stream);
 int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, int32_t T,
                                 int32_t n_head, int32_t* overflow_flag, void* stream);
 /* the same attention (transformer_arch.py:52-67, causal=False, head dim 64) with both
@@ -193,6 +208,9 @@ int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, int32_t B, 
  * (t2h_gemm_split_args.Vt); output as fp32 rows y [B*T, C] and / or split rows y_split. */
 int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,
                       uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag, void* stream);
+/* ... with y_split written in the x8 format (8-bit planes scaled by the power of two `y_scale`) */
+int t2h_mha_split_x8_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, uint16_t* y_x8, float y_scale,
+                         int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag, void* stream);
 /* Two forms, chosen by the number of rounds of the 256 CUs each needs: 128-query workgroups whose two wave groups
  * take the two key halves and merge (what fills the chip at B = 8), or 256-query workgroups whose eight waves each
  * walk all keys (B >= 16: no merge, K / Vt tiles shared by eight waves).  Tuning / tests (thread-local): 1 = all

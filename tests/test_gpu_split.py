@@ -78,7 +78,7 @@ def test_sampler_net_split_matches_oracle_and_fp32_path():
     tex = torch.randint(0, 18, (2, 512), generator=gen)
     args = (idx.to(DEV), seg.to(DEV), tex.to(DEV))
     a = engine.SamplerNet(P, desc, 8, 'tf', split=False).hidden(*args).clone().cpu()
-    b = engine.SamplerNet(P, desc, 8, 'tf', split=True).hidden(*args).clone().cpu()
+    b = engine.SamplerNet(P, desc, 8, 'tf', split=True, x8=False).hidden(*args).clone().cpu()
     with torch.no_grad():
         ref = R.transformer_hidden(idx, seg, tex, sd)
     ln = lambda t: F.layer_norm(t.view(2, 512, 512), (512, ), sd['ln_f.weight'], sd['ln_f.bias'], 1e-5)
@@ -166,7 +166,7 @@ def test_sampler_net_split_mha_on_and_off_agree_with_oracle():
     tex = torch.randint(0, 18, (3, 512), generator=gen)
     args = (idx.to(DEV), seg.to(DEV), tex.to(DEV))
     a = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=False).hidden(*args).clone().cpu()
-    b = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=True).hidden(*args).clone().cpu()
+    b = engine.SamplerNet(P, desc, 8, 'tf', split=True, split_mha=True, x8=False).hidden(*args).clone().cpu()
     with torch.no_grad():
         ref = R.transformer_hidden(idx, seg, tex, sd)
     ln = lambda t: F.layer_norm(t.view(3, 512, 512), (512, ), sd['ln_f.weight'], sd['ln_f.bias'], 1e-5)
@@ -187,7 +187,7 @@ def test_last_layer_tail_on_the_changed_rows_only_matches_the_full_evaluation():
     seg = torch.randint(0, 1024, (2, 512), generator=gen)
     tex = torch.randint(0, 18, (2, 512), generator=gen)
     args = (idx.to(DEV), seg.to(DEV), tex.to(DEV))
-    net = engine.SamplerNet(P, desc, 8, 'tf', split=True)
+    net = engine.SamplerNet(P, desc, 8, 'tf', split=True, x8=False)
     full = net.hidden(*args).clone()
     rows = torch.randperm(1024, generator=gen)[:37].to(torch.int32).to(DEV)
     net.hidden(*args, defer_tail=True)

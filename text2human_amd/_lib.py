@@ -42,6 +42,7 @@ class GemmSplitArgs(ctypes.Structure):
         ('A', c_vp), ('B', c_vp), ('C', c_vp), ('C_split', c_vp), ('bias', c_vp), ('residual', c_vp),
         ('M', c_i32), ('N', c_i32), ('K', c_i32), ('ldc', c_i32), ('ldr', c_i32), ('epi_act', c_i32),
         ('Vt', c_vp), ('vt_col0', c_i32), ('vt_T', c_i32), ('vt_hd', c_i32), ('overflow_flag', c_vp),
+        ('fmt', c_i32), ('out_fmt', c_i32), ('lo_mul', c_f32), ('out_scale', c_f32),
     ]
 
 
@@ -73,6 +74,9 @@ SIGNATURES = {
                                              c_i32, c_i32, c_vp]),
     't2h_conv_split_force_tile': (ctypes.c_int, [ctypes.c_int]),
     't2h_mha_split_force_form': (ctypes.c_int, [ctypes.c_int]),
+    't2h_split_rows_x8_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, ctypes.c_int64, c_i32, c_f32, c_vp, c_vp]),
+    't2h_layernorm_x8_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp]),
+    't2h_mha_split_x8_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     't2h_split_overflow_async': (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp]),
     't2h_split_rows_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
     't2h_layernorm_split_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp]),

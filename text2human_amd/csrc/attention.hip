@@ -278,7 +278,7 @@ template <int KH>
 __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __restrict__ qk, int ld_cols,
                                                         const uint16_t* __restrict__ vt, float* __restrict__ y,
                                                         uint16_t* __restrict__ y_split, int T, int C, int n_head,
-                                                        int* ovf) {
+                                                        int* ovf, float y_x8_scale) {  // y_x8_scale > 0: y_split in the x8 format
   // two (K, Vt) tile pairs per key half (double buffer); reused at the end for the merge + output
   // transpose staging
   constexpr int NQW = 8 / KH;  // waves (x 32 queries) per key half
@@ -578,7 +578,10 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
         *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
         *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
       }
-      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
+      if (y_split) {
+        if (y_x8_scale > 0.f) t2h_store_x8_8<1>(y_split, grow + row, C, head * HD + c8, va, vb, y_x8_scale, ovf);
+        else t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
+      }
     }
   }
   } else {
@@ -604,7 +607,10 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
         *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8) = va;
         *reinterpret_cast<f32x4*>(y + (grow + row) * C + head * HD + c8 + 4) = vb;
       }
-      if (y_split) t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
+      if (y_split) {
+        if (y_x8_scale > 0.f) t2h_store_x8_8<1>(y_split, grow + row, C, head * HD + c8, va, vb, y_x8_scale, ovf);
+        else t2h_store_split8(y_split, grow + row, C, head * HD + c8, va, vb, ovf);
+      }
     }
   }
 #ifdef T2H_MHA_TIMING
@@ -659,9 +665,8 @@ extern "C" int t2h_mha_noncausal_split_f32(const float* qkv, uint16_t* y_split, 
   return T2H_OK;
 }
 
-extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,
-                                 uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag,
-                                 void* stream) {
+static int mha_split_launch(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y, uint16_t* y_split,
+                            float y_x8_scale, int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag, void* stream) {
   T2H_REQUIRE(qk_split && vt && (y || y_split), "t2h_mha_split_f32: NULL pointer");
   T2H_REQUIRE(B > 0 && n_head > 0, "t2h_mha_split_f32: empty problem");
   T2H_REQUIRE(T > 0 && T % QB == 0, "t2h_mha_split_f32: T=%d must be a multiple of %d", T, QB);
@@ -683,12 +688,25 @@ extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, cons
   T2H_REQUIRE(form == 2 || wg1 > 0, "t2h_mha_split_f32: the all-keys form needs T %% 256 == 0");
   if (form == 1)
     hipLaunchKernelGGL(mha_split_pipe_kernel<1>, dim3((unsigned)wg1), block, 0, static_cast<hipStream_t>(stream), qk_split,
-                       ld_cols, vt, y, y_split, T, C, n_head, ovf);
+                       ld_cols, vt, y, y_split, T, C, n_head, ovf, y_x8_scale);
   else
     hipLaunchKernelGGL(mha_split_pipe_kernel<2>, dim3((unsigned)wg2), block, 0, static_cast<hipStream_t>(stream), qk_split,
-                       ld_cols, vt, y, y_split, T, C, n_head, ovf);
+                       ld_cols, vt, y, y_split, T, C, n_head, ovf, y_x8_scale);
   T2H_CHECK_LAUNCH("t2h_mha_split_f32");
   return T2H_OK;
+}
+
+extern "C" int t2h_mha_split_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, float* y,
+                                 uint16_t* y_split, int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag,
+                                 void* stream) {
+  return mha_split_launch(qk_split, ld_cols, vt, y, y_split, 0.f, B, T, n_head, overflow_flag, stream);
+}
+
+extern "C" int t2h_mha_split_x8_f32(const uint16_t* qk_split, int32_t ld_cols, const uint16_t* vt, uint16_t* y_x8,
+                                    float y_scale, int32_t B, int32_t T, int32_t n_head, int32_t* overflow_flag,
+                                    void* stream) {
+  T2H_REQUIRE(y_x8 != nullptr && y_scale > 0.f, "t2h_mha_split_x8_f32: y_x8 is NULL or y_scale <= 0");
+  return mha_split_launch(qk_split, ld_cols, vt, nullptr, y_x8, y_scale, B, T, n_head, overflow_flag, stream);
 }
 
 #ifdef T2H_MHA_TIMING

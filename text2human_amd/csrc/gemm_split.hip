@@ -156,7 +156,26 @@ __device__ __forceinline__ f32x4 gelu_erf_v(f32x4 v) {
 // 256x128 main loop took 1.3 us per K step against 0.77 us of matrix instructions.  (The same
 // schedule with register staging, PP = 1 of round 2, gained nothing and was removed:
 // profiles/r02_gemm_pingpong_ablation_v*.log.)
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int PP>
+//
+// FMT = 1 ("x8" operands, common.h): the low planes of a K tile hold e4m3 copies of h and l instead of the fp16 l:
+// [hi16 | hi8 | lo8].  The hi*hi product is unchanged; the TWO cross terms of a K tile and 32x32 block are ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 (64 cycles instead of 4 x 32): along its K = 64 the A operand is [hi8 | lo8] and the
+// B operand [lo8 | hi8] -- lane (row, h) supplies the 32 bytes of hi8 (h = 0) or lo8 (h = 1), lane (col, h) those of
+// lo8 (h = 0) or hi8 (h = 1), so slot j of half h pairs (ah8[j], bl8[j]) resp. (al8[j], bh8[j]).  Same bytes moved,
+// same fragment reads (two 16-byte reads per lane for the 8-bit operand, as for the fp16 low plane), a third fewer
+// matrix-pipe cycles: fc1 29.6 -> 23.9 us, q|k|v 22.3 -> 19.4 (profiles/r05_cross_term_mx_timing.log).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 x8_cross(const f16x8& a0, const f16x8& a1, const f16x8& b0, const f16x8& b1, const f32x16& c) {
+  union { f16x8 h[2]; i32x8 v; } ua, ub;
+  ua.h[0] = a0;
+  ua.h[1] = a1;
+  ub.h[0] = b0;
+  ub.h[1] = b1;
+  // formats 0 / 0 = e4m3 x e4m3; scales 0x7f = 2^0 (the tensors' power-of-two scales are folded into lo_mul)
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ua.v, ub.v, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int PP, int FMT = 0>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel(const t2h_gemm_split_args p, int* const ovf, long long* const probe) {
   constexpr int NT = 64 * WARPS_M * WARPS_N;  // threads per K group
   constexpr int NWG = WARPS_M * WARPS_N;      // waves per K group
@@ -296,12 +315,18 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     };
     // fragment read offsets inside a tile image: row * 128 + ((plane * 4 + u * 2 + hh) ^ swizzle) * 16
     const int swz = (l31 >> 1) & 7;
+    // (index pl * 2 + u.  FMT 1: "plane 1" = the 8-bit operand of the lane: pieces 4 + 2 h + u for A -- hi8 for
+    // h = 0, lo8 for h = 1 --, 4 + 2 (1 - h) + u for B)
     int offA[4], offB[4];
 #pragma unroll
     for (int c2 = 0; c2 < 4; ++c2) {
       const int pcs = ((c2 * 2 + hh) ^ swz) * 16;
       offA[c2] = (wm0 + l31) * 128 + pcs;
       offB[c2] = (BM + wn0 + l31) * 128 + pcs;
+      if (FMT == 1 && c2 >= 2) {
+        offA[c2] = (wm0 + l31) * 128 + ((4 + 2 * hh + (c2 - 2)) ^ swz) * 16;
+        offB[c2] = (BM + wn0 + l31) * 128 + ((4 + 2 * (1 - hh) + (c2 - 2)) ^ swz) * 16;
+      }
     }
     constexpr int PA[3] = {1, 0, 0};
     constexpr int PB[3] = {0, 1, 0};
@@ -351,6 +376,22 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       // (round 3 tried issuing the requests for tile kt + 2 here instead, one after every fourth matrix
       // instruction: q|k|v 26.4 vs 26.9 us, fc1 30.7 vs 30.6, K = 2048 shapes 10 % slower -- not the
       // request issue cost either; removed.  profiles/r03_gemm_tile_and_dma_placement.log)
+      if constexpr (FMT == 1) {
+        // hi*hi of both k16 steps, then one 8-bit instruction per block for the two cross terms (interleaved so that
+        // consecutive matrix instructions never share an accumulator)
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TN; ++tj) {
+            acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ti][0], bfr[0][tj][0], acc[0][ti][tj], 0, 0, 0);
+            acc[1][ti][tj] = x8_cross(af[0][ti][1], af[1][ti][1], bfr[0][tj][1], bfr[1][tj][1], acc[1][ti][tj]);
+          }
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TN; ++tj)
+            acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ti][0], bfr[1][tj][0], acc[0][ti][tj], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -366,6 +407,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
                                                                            acc[PC[t]][ti][tj], 0, 0, 0);
 #endif
             }
+      }
       if (grp == 0) wait_landed(kt + 2 < nk);  // tile kt + 1
       pp_barrier();
       const unsigned t = b_cur;
@@ -430,6 +472,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   constexpr int PB[3] = {0, 1, 0};
   constexpr int PC[3] = {1, 1, 0};
 
+  constexpr int NMMA_F = FMT == 1 ? 3 * TM * TN : NMMA;  // matrix instructions per wave and K tile in this format
   auto step = [&](int kt, auto setc) {  // register set S holds tile kt+1
     constexpr int S = decltype(setc)::value;
     const int buf = kt & 1;
@@ -437,6 +480,57 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     const char* Ab = gsm + buf * BUF_B + (wm0 + l31) * SP_LDS_ROW + hh * 16;
     const char* Bb = gsm + buf * BUF_B + (BM + wn0 + l31) * SP_LDS_ROW + hh * 16;
     int mma = 0;  // running MFMA count inside the tile (compile-time after unrolling)
+    // staged pieces pinned behind the matrix instructions of the second half of the tile
+    auto pinned = [&]() {
+      ++mma;
+#pragma unroll
+      for (int q = 0; q < L; ++q) {
+        // (more pieces than matrix instructions -- 64x64 tiles on x8 operands: 4 pieces, 3 instructions -- share slots)
+        const int at0 = (2 * L <= NMMA_F) ? NMMA_F - 2 * (L - q) + 1 : (NMMA_F * (q + 1)) / L;
+        const int at = at0 < 1 ? 1 : at0;
+        if (at != mma) continue;
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt16<2 * L - 1>(rg[S][q]);
+        put(q, rg[S][q], buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        gload16_async(rg[S][q], src[q], (q < LA ? gA : gB) + kn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if constexpr (FMT == 1) {
+      // x8 operands: hi16 pieces 2 u + h, 8-bit operand of the lane = pieces 4 + 2 h + j (A: hi8 | lo8) resp.
+      // 4 + 2 (1 - h) + j (B: lo8 | hi8)
+      f16x8 ah[2][TM], a8[2][TM], bh[2][TN], b8[2][TN];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti) {
+          ah[j][ti] = *reinterpret_cast<const f16x8*>(Ab + ti * 32 * SP_LDS_ROW + j * 32);
+          a8[j][ti] = *reinterpret_cast<const f16x8*>(Ab + ti * 32 * SP_LDS_ROW + 64 + hh * 16 + j * 16);
+        }
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) {
+          bh[j][tj] = *reinterpret_cast<const f16x8*>(Bb + tj * 32 * SP_LDS_ROW + j * 32);
+          b8[j][tj] = *reinterpret_cast<const f16x8*>(Bb + tj * 32 * SP_LDS_ROW + 96 - 48 * hh + j * 16);  // (Bb holds + 16 h)
+        }
+      }
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) {
+          acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][ti], bh[0][tj], acc[0][ti][tj], 0, 0, 0);
+          pinned();
+          acc[1][ti][tj] = x8_cross(a8[0][ti], a8[1][ti], b8[0][tj], b8[1][tj], acc[1][ti][tj]);
+          pinned();
+        }
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) {
+          acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][ti], bh[1][tj], acc[0][ti][tj], 0, 0, 0);
+          pinned();
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {  // two k16 steps per K tile
       f16x8 af[TM][2], bfr[TN][2];
@@ -470,21 +564,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
             acc[PC[t]][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ti][PA[t]], bfr[tj][PB[t]],
                                                                          acc[PC[t]][ti][tj], 0, 0, 0);
 #endif
-            ++mma;
-            // staged pieces pinned behind the MFMAs of the second half of the tile
-#pragma unroll
-            for (int q = 0; q < L; ++q) {
-              const int at = (2 * L <= NMMA) ? NMMA - 2 * (L - q) + 1 : (NMMA * (q + 1)) / L;
-              if (at != mma) continue;
-              __builtin_amdgcn_sched_barrier(0);
-              wait_vmcnt16<2 * L - 1>(rg[S][q]);
-              put(q, rg[S][q], buf ^ 1);
-              __builtin_amdgcn_sched_barrier(0);
-              gload16_async(rg[S][q], src[q], (q < LA ? gA : gB) + kn);
-              __builtin_amdgcn_sched_barrier(0);
-            }
+            pinned();
           }
       }
+    }
     }
     __syncthreads();
   };
@@ -510,8 +593,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   float* const Og = Ot + kg * (NWG * OW);                        // this group's
   // value of accumulator register r of MFMA tile (ti, tj) as it is staged: both partial
   // accumulators folded together, plus the bias (K group 0 only)
+  const float lo_mul = FMT == 1 ? p.lo_mul : T2H_SPLIT_LO_INV;  // (x8: 2^-11 over the operands' 8-bit plane scales)
   auto fin = [&](int ti, int tj, int r, float bv) {
-    return fmaf(acc[1][ti][tj][r], T2H_SPLIT_LO_INV, acc[0][ti][tj][r]) + bv;
+    return fmaf(acc[1][ti][tj][r], lo_mul, acc[0][ti][tj][r]) + bv;
   };
   // A tile whose columns straddle vt_col0 (BN = 192 does not divide the q|k / v boundary at 1024) takes
   // both forms of the epilogue, each skipping the other side's columns; tiles of the other shapes lie on
@@ -627,7 +711,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = va;
       *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col + 4) = vb;
     }
-    if (p.C_split) t2h_store_split8(p.C_split, row, p.N, col, va, vb, ovf);
+    if (p.C_split) {
+      if (p.out_fmt == 1) t2h_store_x8_8<1>(p.C_split, row, p.N, col, va, vb, p.out_scale, ovf);  // (lanes 2j, 2j + 1: one 16-column group)
+      else t2h_store_split8(p.C_split, row, p.N, col, va, vb, ovf);
+    }
   }
   G1_MARK(3);
 #ifdef T2H_GEMM_TIMING
@@ -642,6 +729,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 // (tiles w, w + 8, ..) and feed v_mfma_f32_16x16x32_f16 STRAIGHT from global memory -- a lane's
 // fragment of a split row is one 16-byte piece -- and the partial sums meet in LDS, in wave order.
 constexpr int SKINNY_WAVES = 8;
+// FMT = 1 (x8 operands): v_mfma_scale_f32_16x16x128_f8f6f4 contracts 128 slots = 4 lane groups x 32 bytes: TWO K tiles
+// per instruction -- lane group g supplies, for A, hi8 (g = 0) / lo8 (g = 1) of tile t and hi8 (2) / lo8 (3) of tile
+// t + 1, for B lo8 / hi8 / lo8 / hi8 -- next to one v_mfma_f32_16x16x32_f16 per tile for hi*hi.  A wave walks the tile
+// PAIRS w, w + 8, ..; a last unpaired tile (K / 32 odd) contributes zeros for its absent partner.
+typedef int i32x8s __attribute__((ext_vector_type(8)));
+template <int FMT>
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_split_skinny_kernel(const t2h_gemm_split_args p, int* const ovf) {
   __shared__ __attribute__((aligned(16))) float red[SKINNY_WAVES][16 * 16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -652,6 +745,30 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_split_skinny_kernel(co
   const char* ap = reinterpret_cast<const char*>(p.A) + (int64_t)min(m0 + r, p.M - 1) * row_b + kg * 16;
   const char* bp = reinterpret_cast<const char*>(p.B) + (int64_t)min(n0 + r, p.N - 1) * row_b + kg * 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_lo = acc;
+  if constexpr (FMT == 1) {
+    // 8-bit operand of the lane inside a tile: A group g -> plane (g & 1) (hi8, lo8), B -> plane 1 - (g & 1); the
+    // tile of the pair: g >> 1
+    const char* a8 = reinterpret_cast<const char*>(p.A) + (int64_t)min(m0 + r, p.M - 1) * row_b + 64 + (kg & 1) * 32;
+    const char* b8 = reinterpret_cast<const char*>(p.B) + (int64_t)min(n0 + r, p.N - 1) * row_b + 64 + (1 - (kg & 1)) * 32;
+    const int npair = (nk + 1) / 2;
+#pragma unroll 2
+    for (int t2 = wave; t2 < npair; t2 += SKINNY_WAVES) {
+      const int t0 = 2 * t2, tg = t0 + (kg >> 1);
+      const bool have = tg < nk;
+      union { f16x8 h[2]; i32x8s v; } ua, ub;
+      const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      ua.h[0] = have ? *reinterpret_cast<const f16x8*>(a8 + (int64_t)tg * SP_TILE_B) : zero;
+      ua.h[1] = have ? *reinterpret_cast<const f16x8*>(a8 + (int64_t)tg * SP_TILE_B + 16) : zero;
+      ub.h[0] = have ? *reinterpret_cast<const f16x8*>(b8 + (int64_t)tg * SP_TILE_B) : zero;
+      ub.h[1] = have ? *reinterpret_cast<const f16x8*>(b8 + (int64_t)tg * SP_TILE_B + 16) : zero;
+      acc_lo = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ua.v, ub.v, acc_lo, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(ap + (int64_t)t0 * SP_TILE_B),
+                                                   *reinterpret_cast<const f16x8*>(bp + (int64_t)t0 * SP_TILE_B), acc, 0, 0, 0);
+      if (t0 + 1 < nk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(ap + (int64_t)(t0 + 1) * SP_TILE_B),
+                                                     *reinterpret_cast<const f16x8*>(bp + (int64_t)(t0 + 1) * SP_TILE_B), acc, 0, 0, 0);
+    }
+  } else {
 #pragma unroll 4
   for (int t = wave; t < nk; t += SKINNY_WAVES) {
     const f16x8 ah = *reinterpret_cast<const f16x8*>(ap + (int64_t)t * SP_TILE_B);
@@ -662,9 +779,11 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_split_skinny_kernel(co
     acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_lo, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
   }
+  }
+  const float lo_mul = FMT == 1 ? p.lo_mul : T2H_SPLIT_LO_INV;
   // accumulator register e of lane l: row 4 (l >> 4) + e, column l & 15
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[wave][(4 * kg + e) * 16 + r] = fmaf(acc_lo[e], T2H_SPLIT_LO_INV, acc[e]);
+  for (int e = 0; e < 4; ++e) red[wave][(4 * kg + e) * 16 + r] = fmaf(acc_lo[e], lo_mul, acc[e]);
   __syncthreads();
   if (wave != 0) return;
   const int rl = lane >> 2, c4 = (lane & 3) * 4;
@@ -680,7 +799,10 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_split_skinny_kernel(co
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
   if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
   if (p.C) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
-  if (p.C_split) t2h_store_split4(p.C_split, row, p.N, col, v, ovf);
+  if (p.C_split) {
+    if (p.out_fmt == 1) t2h_store_x8_4(p.C_split, row, p.N, col, v, p.out_scale, ovf);
+    else t2h_store_split4(p.C_split, row, p.N, col, v, ovf);
+  }
 }
 
 // fp32 [rows, C] (ld) -> split rows; one thread per 4 consecutive columns
@@ -692,6 +814,17 @@ __global__ void split_rows_kernel(const float* __restrict__ x, int ldx, uint16_t
   const int64_t row = i / q;
   const int c0 = (int)(i - row * q) * 4;
   t2h_store_split4(out, row, C, c0, *reinterpret_cast<const f32x4*>(x + row * ldx + c0), ovf);
+}
+
+// fp32 [rows, C] (ld) -> x8 rows (common.h); one thread per 4 consecutive columns
+__global__ void split_rows_x8_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ out, int64_t total,
+                                     int C, float scale, int* ovf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int q = C >> 2;
+  const int64_t row = i / q;
+  const int c0 = (int)(i - row * q) * 4;
+  t2h_store_x8_4(out, row, C, c0, *reinterpret_cast<const f32x4*>(x + row * ldx + c0), scale, ovf);
 }
 
 // t2h_gemm_split_time_next_launch: events that receive the START and the END of the next kernel this
@@ -711,7 +844,7 @@ void launch_maybe_timed(K kernel, dim3 grid, dim3 block, hipStream_t s, Args... 
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1, int PP = 0>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS = 1, int PP = 0, int FMT = 0>
 int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
   T2H_REQUIRE(a.K % (32 * KS) == 0, "t2h_gemm_split_f32: this tile config needs K %% %d == 0", 32 * KS);
   if (a.Vt)
@@ -721,7 +854,7 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
               "t2h_gemm_split_f32: operands are addressed with 32-bit byte offsets (each must span < 2 GiB)");
   dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
   int* ovf = a.overflow_flag;
-  launch_maybe_timed(gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP>, grid, dim3(64 * WARPS_M * WARPS_N * KS), s, a,
+  launch_maybe_timed(gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP, FMT>, grid, dim3(64 * WARPS_M * WARPS_N * KS), s, a,
                      ovf, g_probe);
   T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
   return T2H_OK;
@@ -815,26 +948,56 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
                     a.vt_col0 < a.N && (a.N - a.vt_col0) % a.vt_hd == 0 && a.epi_act == 0 && !a.residual,
                 "t2h_gemm_split_f32: bad Vt routing (col0=%d T=%d hd=%d M=%d N=%d)", a.vt_col0, a.vt_T, a.vt_hd,
                 a.M, a.N);
+  T2H_REQUIRE((a.fmt == 0 || a.fmt == 1) && (a.out_fmt == 0 || a.out_fmt == 1), "t2h_gemm_split_f32: fmt / out_fmt must be 0 or 1");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  t2h_gemm_split_args ax = a;
+  if (ax.lo_mul == 0.f) ax.lo_mul = T2H_SPLIT_LO_INV;
+  if (ax.out_scale == 0.f) ax.out_scale = 1.0f;
   const int cfg = pick_split_cfg(a);
   if (cfg == 9) {
     const bool skinny_ok = a.N % 16 == 0 && !a.Vt && (a.bias == nullptr || t2h_aligned16(a.bias));
     T2H_REQUIRE(skinny_ok, "t2h_gemm_split_f32: the few-rows kernel needs N %% 16 == 0 and no Vt routing");
     int* ovf = a.overflow_flag;
-    launch_maybe_timed(gemm_split_skinny_kernel, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), s, a, ovf);
+    if (a.fmt == 1)
+      launch_maybe_timed(gemm_split_skinny_kernel<1>, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), s, ax, ovf);
+    else
+      launch_maybe_timed(gemm_split_skinny_kernel<0>, dim3(a.N / 16, (a.M + 15) / 16), dim3(64 * SKINNY_WAVES), s, ax, ovf);
     T2H_CHECK_LAUNCH("t2h_gemm_split_f32");
     return T2H_OK;
   }
-  switch (cfg) {
-    case 1: return launch_split<128, 128, 4, 2>(a, s);  // 8 waves, wave tile 32x64
-    case 2: return launch_split<64, 64, 2, 2>(a, s);    // 4 waves, wave tile 32x32
-    case 3: return launch_split<128, 64, 4, 2>(a, s);   // 8 waves, wave tile 32x32
-    case 5: return launch_split<128, 256, 4, 2>(a, s);  // 8 waves, wave tile 32x128
-    case 6: return launch_split<128, 64, 2, 2, 2>(a, s);  // 2 K groups x 4 waves, wave tile 64x32
-    case 8: return launch_split<256, 128, 4, 2, 1, 2>(a, s);  // 8 waves, wave tile 64x64, ping-pong LDS-DMA loop
-    case 10: return launch_split<128, 192, 4, 2, 1, 2>(a, s);  // 8 waves, wave tile 32x96, the same loop
-    default: return launch_split<128, 64, 2, 2>(a, s);  // 4 waves, wave tile 64x32
+  if (a.fmt == 1) {  // x8 operands: the tile configurations the sampler's shapes take
+    switch (cfg) {
+      case 2: return launch_split<64, 64, 2, 2, 1, 0, 1>(ax, s);
+      case 6: return launch_split<128, 64, 2, 2, 2, 0, 1>(ax, s);
+      case 8: return launch_split<256, 128, 4, 2, 1, 2, 1>(ax, s);
+      case 10: return launch_split<128, 192, 4, 2, 1, 2, 1>(ax, s);
+      case 0: return launch_split<128, 64, 2, 2, 1, 0, 1>(ax, s);
+      default:
+        t2h_set_error("t2h_gemm_split_f32: tile configuration %d is not built for x8 operands (0, 2, 6, 8, 9, 10)", cfg);
+        return T2H_ERR_INVALID;
+    }
   }
+  switch (cfg) {
+    case 1: return launch_split<128, 128, 4, 2>(ax, s);  // 8 waves, wave tile 32x64
+    case 2: return launch_split<64, 64, 2, 2>(ax, s);    // 4 waves, wave tile 32x32
+    case 3: return launch_split<128, 64, 4, 2>(ax, s);   // 8 waves, wave tile 32x32
+    case 5: return launch_split<128, 256, 4, 2>(ax, s);  // 8 waves, wave tile 32x128
+    case 6: return launch_split<128, 64, 2, 2, 2>(ax, s);  // 2 K groups x 4 waves, wave tile 64x32
+    case 8: return launch_split<256, 128, 4, 2, 1, 2>(ax, s);  // 8 waves, wave tile 64x64, ping-pong LDS-DMA loop
+    case 10: return launch_split<128, 192, 4, 2, 1, 2>(ax, s);  // 8 waves, wave tile 32x96, the same loop
+    default: return launch_split<128, 64, 2, 2>(ax, s);  // 4 waves, wave tile 64x32
+  }
+}
+
+extern "C" int t2h_split_rows_x8_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, float scale,
+                                     int32_t* overflow_flag, void* stream) {
+  T2H_REQUIRE(x && out && rows > 0 && C > 0 && C % 32 == 0 && ldx % 4 == 0 && scale > 0.f, "t2h_split_rows_x8_f32: bad arguments");
+  T2H_REQUIRE(overflow_flag != nullptr, "t2h_split_rows_x8_f32: overflow_flag is NULL");
+  const int64_t total = rows * (C / 4);
+  hipLaunchKernelGGL(split_rows_x8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, ldx, out, total, C, scale, overflow_flag);
+  T2H_CHECK_LAUNCH("t2h_split_rows_x8_f32");
+  return T2H_OK;
 }
 
 extern "C" int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C,

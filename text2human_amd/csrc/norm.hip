@@ -11,12 +11,13 @@ namespace {
 #define T2H_LN_RPB 8  // rows (= waves) per workgroup: with the input just written by the previous kernel,
                       // 6.3 us at 8 against 7.3 at 4, 6.6 at 2 / 16 (tools/ln_block_bench.py)
 #endif
-template <int VPL, bool SPLIT = false>  // float4 vectors per lane: C = 256 * VPL
+// SPLIT = 2: the x8 format (common.h: fp16 plane + two e4m3 planes scaled by `x8_scale`).
+template <int VPL, int SPLIT = 0>  // float4 vectors per lane: C = 256 * VPL
 __global__ __launch_bounds__(64 * T2H_LN_RPB) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         float* __restrict__ y, int rows,
-                                                        float eps, int* ovf) {
+                                                        float eps, int* ovf, float x8_scale = 1.0f) {
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * T2H_LN_RPB + (threadIdx.x >> 6);
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(64 * T2H_LN_RPB) void layernorm_kernel(const float*
     v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
     s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
-  const float mean = wave_sum(s) * (1.0f / C);
+  const float mean = wave_sum_dpp(s) * (1.0f / C);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i)
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(64 * T2H_LN_RPB) void layernorm_kernel(const float*
       const float d = v[i][e] - mean;
       q = fmaf(d, d, q);
     }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+  const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * (1.0f / C) + eps);
   float* yr = y + (int64_t)row * C;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(64 * T2H_LN_RPB) void layernorm_kernel(const float*
     // plane) -- the even lane slab i, the odd lane slab i+1
     static_assert(VPL % 2 == 0 || VPL == 1, "pairwise slab exchange");
     if (VPL == 1) {
-      t2h_store_split4(reinterpret_cast<uint16_t*>(y), row, C, lane * 4, v[0], ovf);
+      if (SPLIT == 2) t2h_store_x8_4(reinterpret_cast<uint16_t*>(y), row, C, lane * 4, v[0], x8_scale, ovf);
+      else t2h_store_split4(reinterpret_cast<uint16_t*>(y), row, C, lane * 4, v[0], ovf);
     } else {
 #pragma unroll
       for (int i = 0; i < VPL; i += 2) {
@@ -67,7 +69,11 @@ __global__ __launch_bounds__(64 * T2H_LN_RPB) void layernorm_kernel(const float*
           send[e] = odd ? v[i][e] : v[i + 1][e];
           recv[e] = __shfl_xor(send[e], 1, 64);
         }
-        if (!odd) t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, i * 256 + lane * 4, v[i], recv, ovf);
+        if (SPLIT == 2) {
+          // (lanes l, l ^ 2 hold the two halves of a 16-column group of the same slab)
+          if (!odd) t2h_store_x8_8<2>(reinterpret_cast<uint16_t*>(y), row, C, i * 256 + lane * 4, v[i], recv, x8_scale, ovf);
+          else t2h_store_x8_8<2>(reinterpret_cast<uint16_t*>(y), row, C, (i + 1) * 256 + (lane - 1) * 4, recv, v[i + 1], x8_scale, ovf);
+        } else if (!odd) t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, i * 256 + lane * 4, v[i], recv, ovf);
         else t2h_store_split8(reinterpret_cast<uint16_t*>(y), row, C, (i + 1) * 256 + (lane - 1) * 4, recv, v[i + 1], ovf);
       }
     }
@@ -263,9 +269,9 @@ extern "C" int t2h_layernorm_f32(const float* x, const float* gamma, const float
               "t2h_layernorm_f32: 16-byte alignment");
   dim3 grid((rows + T2H_LN_RPB - 1) / T2H_LN_RPB), block(64 * T2H_LN_RPB);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (C == 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr));
-  else if (C == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr));
-  else if (C == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr));
+  if (C == 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr), 1.0f);
+  else if (C == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr), 1.0f);
+  else if (C == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, eps, static_cast<int*>(nullptr), 1.0f);
   else {
     t2h_set_error("t2h_layernorm_f32: C=%d unsupported (256/512/1024)", C);
     return T2H_ERR_UNSUPPORTED;
@@ -286,14 +292,35 @@ extern "C" int t2h_layernorm_split_f32(const float* x, const float* gamma, const
   float* y = reinterpret_cast<float*>(y_split);
   int* ovf = overflow_flag;
   T2H_REQUIRE(ovf != nullptr, "t2h_layernorm_split_f32: overflow_flag is NULL");
-  if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
-  else if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
-  else if (C == 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf);
+  if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, 1>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf, 1.0f);
+  else if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, 1>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf, 1.0f);
+  else if (C == 1024) hipLaunchKernelGGL((layernorm_kernel<4, 1>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf, 1.0f);
   else {
     t2h_set_error("t2h_layernorm_split_f32: C=%d unsupported (256/512/1024)", C);
     return T2H_ERR_UNSUPPORTED;
   }
   T2H_CHECK_LAUNCH("t2h_layernorm_split_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_layernorm_x8_f32(const float* x, const float* gamma, const float* beta, uint16_t* y_x8, int32_t rows,
+                                    int32_t C, float eps, float scale, int32_t* overflow_flag, void* stream) {
+  T2H_REQUIRE(x && gamma && beta && y_x8 && overflow_flag, "t2h_layernorm_x8_f32: NULL pointer");
+  T2H_REQUIRE(rows > 0 && scale > 0.f, "t2h_layernorm_x8_f32: rows=%d scale=%g", rows, (double)scale);
+  T2H_REQUIRE(t2h_aligned16(x) && t2h_aligned16(y_x8) && t2h_aligned16(gamma) && t2h_aligned16(beta),
+              "t2h_layernorm_x8_f32: 16-byte alignment");
+  dim3 grid((rows + T2H_LN_RPB - 1) / T2H_LN_RPB), block(64 * T2H_LN_RPB);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* y = reinterpret_cast<float*>(y_x8);
+  int* ovf = overflow_flag;
+  if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, 2>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf, scale);
+  else if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, 2>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf, scale);
+  else if (C == 1024) hipLaunchKernelGGL((layernorm_kernel<4, 2>), grid, block, 0, s, x, gamma, beta, y, rows, eps, ovf, scale);
+  else {
+    t2h_set_error("t2h_layernorm_x8_f32: C=%d unsupported (256/512/1024)", C);
+    return T2H_ERR_UNSUPPORTED;
+  }
+  T2H_CHECK_LAUNCH("t2h_layernorm_x8_f32");
   return T2H_OK;
 }
 

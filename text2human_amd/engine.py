@@ -179,10 +179,18 @@ class SamplerNet:
     tail kernel.  24 x [LN, QKV GEMM, flash MHA, proj GEMM(+res), LN, fc1
     GEMM(+GELU), fc2 GEMM(+res)]."""
 
-    def __init__(self, P, desc, n_head, name='tf', split=False, split_mha=True):
+    def __init__(self, P, desc, n_head, name='tf', split=False, split_mha=True, x8=None):
         self.P, self.desc, self.n_head, self.name = P, desc, n_head, name
         self.split = split
         self._deferred = None
+        # x8 (default with the split path; T2H_X8=0 opts out): the four Linears read "x8" operands -- fp16 plane +
+        # two e4m3 planes (csrc/common.h) -- and run both cross terms of a K tile in ONE 8-bit matrix instruction
+        # (a third fewer matrix-pipe cycles; tools/cross_term_emulation.py: the hidden state moves by 4e-5 against a
+        # tolerance of 2e-4).  Needs per-tensor power-of-two scales: weights from their own maximum, activations from
+        # a calibration evaluation on the first input (_x8_prepare); a value beyond a scale's range raises bit 1 of
+        # the overflow word and the caller re-runs on the fp16 planes (X8RangeError).
+        self.x8 = bool(split and split_mha and os.environ.get('T2H_X8', '1') != '0') if x8 is None else bool(x8)
+        self._x8 = None  # {'w': {(layer, lin): scale}, 'a': {(layer, role): scale}} once prepared
         # split_mha (with split): attention on the fp16 matrix cores too -- the q|k|v
         # projection writes q, k as split rows and v as transposed planes, no fp32 qkv
         self.split_mha = split_mha
@@ -247,6 +255,29 @@ class SamplerNet:
             hs, ys, us, qks = buf['h_split'], buf['y_split'], buf['u_split'], buf['qk_split']
             vt = buf['vt']
             hd = C // self.n_head
+            if self.x8 and self.split_mha:
+                if self._x8 is None:
+                    self._x8_prepare(idx, segm_tok, tex_tok, buf)
+                    ops.embed_sum4(idx, segm_tok, tex_tok, P[f'{nm}.tok_emb'], P[f'{nm}.pos_emb'],
+                                   P[f'{nm}.segm_emb'], P[f'{nm}.tex_emb'], out=x)  # (the calibration overwrote x)
+                sw, sa = self._x8['w'], self._x8['a']
+                for i in range(L):
+                    p = f'{nm}.{i}'
+                    ops.layernorm_x8(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs, sa[i, 'h1'])
+                    ops.gemm_split(hs, P[f'{p}.qkv.w_x8'], M, 3 * C, C, out_split=qks, bias=P[f'{p}.qkv.b'],
+                                   vt=vt, vt_col0=2 * C, vt_T=T, vt_hd=hd, x8=(sa[i, 'h1'], sw[i, 'qkv']))
+                    ops.mha_split_x8(qks, 3 * C, vt, B, T, self.n_head, ys, sa[i, 'y'])
+                    if i == L - 1 and defer_tail:
+                        self._deferred = (full['x'], full['y_split'], M, C)
+                        return x
+                    ops.gemm_split(ys, P[f'{p}.proj.w_x8'], M, C, C, out=x, bias=P[f'{p}.proj.b'], residual=x,
+                                   x8=(sa[i, 'y'], sw[i, 'proj']))
+                    ops.layernorm_x8(x, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs, sa[i, 'h2'])
+                    ops.gemm_split(hs, P[f'{p}.fc1.w_x8'], M, 4 * C, C, out_split=us, bias=P[f'{p}.fc1.b'],
+                                   act=ACT_GELU, x8=(sa[i, 'h2'], sw[i, 'fc1']), out_x8_scale=sa[i, 'u'])
+                    ops.gemm_split(us, P[f'{p}.fc2.w_x8'], M, C, 4 * C, out=x, bias=P[f'{p}.fc2.b'], residual=x,
+                                   x8=(sa[i, 'u'], sw[i, 'fc2']))
+                return x
             for i in range(L):
                 p = f'{nm}.{i}'
                 ops.layernorm_split(x, P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs)
@@ -295,11 +326,74 @@ class SamplerNet:
         else:
             m, xc, yc, compact = M, x, ys, False
             hc, uc = buf['h_split'], buf['u_split']
+        if self.x8 and self._x8 is not None:
+            i = self.desc['n_layers'] - 1
+            sw, sa = self._x8['w'], self._x8['a']
+            ops.gemm_split(yc, P[f'{p}.proj.w_x8'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc,
+                           x8=(sa[i, 'y'], sw[i, 'proj']))
+            ops.layernorm_x8(xc, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hc, sa[i, 'h2'])
+            ops.gemm_split(hc, P[f'{p}.fc1.w_x8'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.b'], act=ACT_GELU,
+                           x8=(sa[i, 'h2'], sw[i, 'fc1']), out_x8_scale=sa[i, 'u'])
+            ops.gemm_split(uc, P[f'{p}.fc2.w_x8'], m, C, 4 * C, out=xc, bias=P[f'{p}.fc2.b'], residual=xc,
+                           x8=(sa[i, 'u'], sw[i, 'fc2']))
+            return xc, compact
         ops.gemm_split(yc, P[f'{p}.proj.w_split'], m, C, C, out=xc, bias=P[f'{p}.proj.b'], residual=xc)
         ops.layernorm_split(xc, P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hc)
         ops.gemm_split(hc, P[f'{p}.fc1.w_split'], m, 4 * C, C, out_split=uc, bias=P[f'{p}.fc1.b'], act=ACT_GELU)
         ops.gemm_split(uc, P[f'{p}.fc2.w_split'], m, C, 4 * C, out=xc, bias=P[f'{p}.fc2.b'], residual=xc)
         return xc, compact
+
+    def ensure_x8(self, segm_tok, tex_tok, mask_id):
+        """Weights packed and activation scales calibrated before the first sampling round (and before any graph
+        capture): one evaluation of the all-masked state this run starts from."""
+        if self.x8 and self.split and self.split_mha and self._x8 is None:
+            self.hidden(torch.full_like(segm_tok, mask_id), segm_tok, tex_tok)
+
+    def _x8_prepare(self, idx, segm_tok, tex_tok, buf):
+        """One-time set-up of the x8 path (init-time plumbing, not on the sampling path): (1) the four Linears' weights
+        as x8 rows, each matrix with the power-of-two scale that puts its own maximum into [128, 256); (2) the
+        activation scales: ONE evaluation on the fp16-plane kernels of this input and of a random-token state, the
+        maximum of every producer's output (LayerNorm 1 / 2, attention, GELU) per layer read from the fp16 plane,
+        each scaled into [16, 32) -- 14x headroom before the 8-bit planes saturate, full 4-bit precision down to
+        2^-10 of the maximum."""
+        P, nm, C, L = self.P, self.name, self.desc['C'], self.desc['n_layers']
+        sw, sa = {}, {}
+        for i in range(L):
+            for lin in ('qkv', 'proj', 'fc1', 'fc2'):
+                w = P[f'{nm}.{i}.{lin}.w']
+                sw[i, lin] = ops.x8_scale_for(float(w.abs().max()), 256.0)
+                if f'{nm}.{i}.{lin}.w_x8' not in P.t:
+                    P.t[f'{nm}.{i}.{lin}.w_x8'] = ops.split_rows_x8(w, sw[i, lin])
+        B, T = idx.shape
+        M = B * T
+        hi_max = lambda sp, rows: float(sp[:rows].view(torch.float16)[:, :, 0, :].abs().max())
+        mx = {}
+        g = torch.Generator(device='cpu').manual_seed(1)
+        rnd = (torch.randint(0, P[f'{nm}.heads'].shape[1], (B, T), generator=g).to(idx.device) +
+               P[f'{nm}.heads'].shape[1] * tex_tok).clamp_(max=P[f'{nm}.tok_emb'].shape[0] - 1)
+        x, hs, ys, us, qks, vt = buf['x'], buf['h_split'], buf['y_split'], buf['u_split'], buf['qk_split'], buf['vt']
+        hd = C // self.n_head
+        for state in (idx, rnd):
+            ops.embed_sum4(state, segm_tok, tex_tok, P[f'{nm}.tok_emb'], P[f'{nm}.pos_emb'], P[f'{nm}.segm_emb'],
+                           P[f'{nm}.tex_emb'], out=x[:M])
+            for i in range(L):
+                p = f'{nm}.{i}'
+                ops.layernorm_split(x[:M], P[f'{p}.ln1.g'], P[f'{p}.ln1.b'], hs)
+                mx[i, 'h1'] = max(mx.get((i, 'h1'), 0.0), hi_max(hs, M))
+                ops.gemm_split(hs, P[f'{p}.qkv.w_split'], M, 3 * C, C, out_split=qks, bias=P[f'{p}.qkv.b'], vt=vt[:B],
+                               vt_col0=2 * C, vt_T=T, vt_hd=hd)
+                ops.mha_split(qks, 3 * C, vt[:B], B, T, self.n_head, out_split=ys)
+                mx[i, 'y'] = max(mx.get((i, 'y'), 0.0), hi_max(ys, M))
+                ops.gemm_split(ys, P[f'{p}.proj.w_split'], M, C, C, out=x[:M], bias=P[f'{p}.proj.b'], residual=x[:M])
+                ops.layernorm_split(x[:M], P[f'{p}.ln2.g'], P[f'{p}.ln2.b'], hs)
+                mx[i, 'h2'] = max(mx.get((i, 'h2'), 0.0), hi_max(hs, M))
+                ops.gemm_split(hs, P[f'{p}.fc1.w_split'], M, 4 * C, C, out_split=us, bias=P[f'{p}.fc1.b'], act=ACT_GELU)
+                mx[i, 'u'] = max(mx.get((i, 'u'), 0.0), hi_max(us, M))
+                ops.gemm_split(us, P[f'{p}.fc2.w_split'], M, C, 4 * C, out=x[:M], bias=P[f'{p}.fc2.b'], residual=x[:M])
+        check_split_overflow('index sampler (x8 calibration)')
+        for k, v in mx.items():
+            sa[k] = ops.x8_scale_for(v)
+        self._x8 = {'w': sw, 'a': sa, 'act_max': mx}
 
     def logits(self, idx, segm_tok, tex_tok, heads=None):
         """Full [B*T, 1024] logits per head (tests / API parity only; the
@@ -373,11 +467,21 @@ class SplitOverflowError(_lib.T2HError):
     """An activation of the split-precision sampler left fp16's range."""
 
 
+class X8RangeError(SplitOverflowError):
+    """An activation of the x8 path left the range its calibrated scale gives the 8-bit planes (the fp16 planes are
+    fine): the caller re-runs on the fp16-plane kernels."""
+
+
 def check_split_overflow(what='sampler', knob='T2H_SPLIT_GEMM'):
     """Raises if a split-row producer flagged |x| >= 65504 since the last check (the fp16
-    planes would hold inf / NaN).  There is deliberately no silent fallback: the caller reruns
-    with the exact-fp32 kernels."""
-    if ops.split_overflow(reset=True):
+    planes would hold inf / NaN) -- SplitOverflowError, the caller reruns with the exact-fp32 kernels -- or a value
+    outside an x8 tensor's 8-bit range -- X8RangeError, the caller reruns on the fp16 planes."""
+    bits = ops.split_overflow_bits(reset=True)
+    if bits & 1 == 0 and bits & 2:
+        raise X8RangeError(f'{what}: an activation exceeded 14x its calibration maximum, outside the range of the x8 '
+                           'format\'s 8-bit planes (include/t2h_hip.h); the result is invalid.  Rerun with T2H_X8=0 '
+                           '(fp16 planes).')
+    if bits:
         raise SplitOverflowError(
             f'{what}: an activation reached |x| >= 65504, outside the range of the 2 x fp16 split '
             f'representation (include/t2h_hip.h); the result is invalid.  Rerun with {knob}=0 '
@@ -617,6 +721,9 @@ def sample_tokens(net, segm_tok, tex_tok, sample_steps, mask_id, temp=1.0, noise
     tex_flat = tex_tok.reshape(-1).contiguous()
     # finished samples leave the batch (T2H_SHRINK_BATCH=0 opts out; hooks see the batch in its own order)
     shrink = (compact and step_hook is None and round_hook is None and os.environ.get('T2H_SHRINK_BATCH', '1') != '0')
+    if split and getattr(net, 'x8', False):
+        net.ensure_x8(segm_tok, tex_tok, mask_id)
+        ops.split_overflow(reset=True)
     sched = build_schedule(tex_tok, sample_steps, n_books, n_class, noise, compact, shrink)
     defer = bool(split and getattr(net, 'split_mha', False) and os.environ.get('T2H_TRIM_LAST_LAYER', '1') != '0')
     # (only the deferred-tail form of hidden() runs on the prefix of running samples; every other form evaluates the

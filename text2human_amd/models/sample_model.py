@@ -112,15 +112,25 @@ class BaseSampleModel():
         # run THIS call on the exact-fp32 kernels (same schedule, same draws, the reference's tokens).
         gen = torch.cuda.default_generators[self.device.index]
         state = gen.get_state()
-        try:
-            out = engine.sample_tokens(self.sampler_fn, self.segm_tokens.contiguous(), tex_tok,
-                                       sample_steps, self.mask_id, temp=temp, noise=self.noise)
-        except engine.SplitOverflowError as e:
-            if not _overflow_fallback('index sampler', 'T2H_SPLIT_GEMM', e):
-                raise
-            gen.set_state(state)
-            out = engine.sample_tokens(self._exact_sampler(), self.segm_tokens.contiguous(), tex_tok,
-                                       sample_steps, self.mask_id, temp=temp, noise=self.noise)
+        net = self.sampler_fn
+        for _ in range(3):  # x8 planes -> fp16 planes -> exact fp32, each at most once
+            try:
+                out = engine.sample_tokens(net, self.segm_tokens.contiguous(), tex_tok, sample_steps, self.mask_id,
+                                           temp=temp, noise=self.noise)
+                break
+            except engine.X8RangeError as e:
+                # an activation beyond 14x its calibration maximum: the 8-bit planes saturated, the fp16 planes are
+                # fine -- this net continues on the fp16-plane kernels (about 15 % slower), from the same generator state
+                if not _overflow_fallback('index sampler (x8 range)', 'T2H_X8', e, 'fp16-plane'):
+                    raise
+                net.x8 = False
+                net._graphs = {}
+                gen.set_state(state)
+            except engine.SplitOverflowError as e:
+                if net is not self.sampler_fn or not _overflow_fallback('index sampler', 'T2H_SPLIT_GEMM', e):
+                    raise
+                gen.set_state(state)
+                net = self._exact_sampler()
         b = self.batch_size
         return [out[i].view(b, -1) for i in range(out.shape[0])]
 
@@ -244,15 +254,15 @@ class BaseSampleModel():
 _warned = set()
 
 
-def _overflow_fallback(stage, knob, err):
-    """True: re-run the stage on the exact-fp32 kernels (default; warns once per stage).  T2H_OVERFLOW_FALLBACK=0:
+def _overflow_fallback(stage, knob, err, to='exact-fp32'):
+    """True: re-run the stage on the `to` kernels (default; warns once per stage).  T2H_OVERFLOW_FALLBACK=0:
     the SplitOverflowError propagates, as before."""
     if os.environ.get('T2H_OVERFLOW_FALLBACK', '1') == '0':
         return False
     if stage not in _warned:
         _warned.add(stage)
         import warnings
-        warnings.warn(f'text2human_amd: {err}  Re-running the {stage} on the exact-fp32 kernels (about 2x slower); '
+        warnings.warn(f'text2human_amd: {err}  Re-running the {stage} on the {to} kernels; '
                       f'set {knob}=0 to start there, T2H_OVERFLOW_FALLBACK=0 to raise instead.')
     return True
 

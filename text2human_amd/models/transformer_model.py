@@ -33,7 +33,7 @@ class TransformerTextureAwareModel():
             P.put(f'{nm}.w', weights.pack_conv1x1(sds[key]['weight']))
             P.put(f'{nm}.b', sds[key]['bias'])
         d_tf = weights.pack_transformer(P, sds['sampler'], 'tf')
-        self._denoise_fn = engine.SamplerNet(P, d_tf, opt['bert_n_head'], 'tf', split=True)
+        self._denoise_fn = engine.SamplerNet(P, d_tf, opt['bert_n_head'], 'tf', split=True, x8=False)  # (loss values: fp16 planes)
         self.shape = tuple(opt['latent_shape'])
         self.num_timesteps = 1000  # transformer_model.py:99
         self.mask_id = opt['codebook_size']

@@ -405,15 +405,74 @@ def pack_split_rows_host(w):
     return planes.view(torch.int16)
 
 
+X8_TARGET_MAX = 32.0  # a tensor's calibration maximum is scaled into [16, 32): 14x headroom below e4m3's 448
+
+
+def x8_scale_for(max_abs, target=X8_TARGET_MAX):
+    """The power of two s with max_abs * s in [target / 2, target): the scale of a tensor's 8-bit planes (x8 format,
+    csrc/common.h).  Weights use target 256 (their maximum is known exactly when they are packed)."""
+    import math
+    m = float(max_abs)
+    if not (m > 0.0) or not math.isfinite(m):
+        return 1.0
+    return 2.0 ** (math.ceil(math.log2(target / m)) - 1)
+
+
+def split_rows_x8(x, scale, out=None):
+    """fp32 x [rows, C] -> x8 rows [rows][C/32][hi16 | hi8 | lo8] (same byte size as split rows), 8-bit planes
+    scaled by the power of two `scale`."""
+    _chk_f32(x)
+    rows, C = x.shape
+    if out is None:
+        out = split_rows_empty(rows, C, x.device)
+    check(_lib.load().t2h_split_rows_x8_f32(_p(x), _rows(x), _p(out), rows, C, float(scale), overflow_flag(), _stream()),
+          't2h_split_rows_x8_f32')
+    return out
+
+
+def unpack_x8_rows_host(s, rows, C, scale):
+    """x8 rows (int16 view, any device) -> (hi fp32 [rows, C], hi8 / scale, lo8 / scale) on the CPU: the three planes
+    as the numbers they stand for (tests)."""
+    raw = s.cpu().contiguous().view(torch.uint8).view(rows, C // 32, 128)
+    hi = raw[:, :, :64].contiguous().view(torch.float16).float().reshape(rows, C)
+    h8 = raw[:, :, 64:96].contiguous().view(torch.float8_e4m3fn).float().reshape(rows, C) / scale
+    l8 = raw[:, :, 96:].contiguous().view(torch.float8_e4m3fn).float().reshape(rows, C) / scale
+    return hi, h8, l8
+
+
+def layernorm_x8(x, gamma, beta, out_x8, scale, eps=1e-5):
+    """LayerNorm whose result is written in the x8 format."""
+    _chk_f32(x, gamma, beta)
+    assert x.is_contiguous()
+    rows, C = x.shape
+    check(_lib.load().t2h_layernorm_x8_f32(_p(x), _p(gamma), _p(beta), _p(out_x8), rows, C, eps, float(scale),
+                                           overflow_flag(), _stream()), 't2h_layernorm_x8_f32')
+    return out_x8
+
+
+def mha_split_x8(qk_split, ld_cols, vt, B, T, n_head, out_x8, scale):
+    """mha_split with the output written in the x8 format."""
+    check(_lib.load().t2h_mha_split_x8_f32(_p(qk_split), ld_cols, _p(vt), _p(out_x8), float(scale), B, T, n_head,
+                                           overflow_flag(), _stream()), 't2h_mha_split_x8_f32')
+    return out_x8
+
+
 def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE,
-               vt=None, vt_col0=0, vt_T=0, vt_hd=64):
+               vt=None, vt_col0=0, vt_T=0, vt_hd=64, x8=None, out_x8_scale=None):
     """C = act(A @ W^T + bias) + residual on the fp16 matrix cores at fp32-class
     accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
     split-row form `out_split` of the result.  With `vt` the output columns from
     `vt_col0` on go to the transposed value planes of mha_split instead
-    (t2h_gemm_split_args.Vt)."""
+    (t2h_gemm_split_args.Vt).
+    x8 = (scale_A, scale_B): the operands are x8 rows (fp16 plane + two e4m3 planes scaled by those powers of two),
+    the cross terms run on the 8-bit matrix instruction; out_x8_scale: `out_split` is written in the x8 format."""
     _chk_f32(out, bias, residual)
     g = _lib.GemmSplitArgs()
+    if x8 is not None:
+        g.fmt = 1
+        g.lo_mul = 1.0 / (SPLIT_LO_SCALE * float(x8[0]) * float(x8[1]))
+    if out_x8_scale is not None:
+        g.out_fmt, g.out_scale = 1, float(out_x8_scale)
     g.A, g.B = a_split.data_ptr(), w_split.data_ptr()
     g.C = out.data_ptr() if out is not None else None
     g.C_split = out_split.data_ptr() if out_split is not None else None
@@ -470,13 +529,18 @@ def split_overflow_async(reset=True):
     return host
 
 
-def split_overflow(reset=True):
-    """True if any split-row producer launched on the current stream met a value outside fp16's range
-    (|x| >= 65504) since the last reset (sticky device word, include/t2h_hip.h).  Synchronises the current
-    stream -- here, in the host code, not inside the library."""
+def split_overflow_bits(reset=True):
+    """The sticky overflow word of the current stream's split-row producers since the last reset (include/t2h_hip.h):
+    bit 0: a value outside fp16's range (|x| >= 65504); bit 1: a value outside the 8-bit planes' range of an x8
+    tensor (|x| s >= 448).  Synchronises the current stream -- here, in the host code, not inside the library."""
     host = split_overflow_async(reset)
     torch.cuda.current_stream().synchronize()
-    return bool(int(host[0]))
+    return int(host[0])
+
+
+def split_overflow(reset=True):
+    """True if any split-row producer flagged a value since the last reset (any bit of split_overflow_bits)."""
+    return bool(split_overflow_bits(reset))
 
 
 def vt_empty(B, n_head, T, device, hd=64):

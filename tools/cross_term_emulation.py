@@ -44,6 +44,29 @@ def q_e4m3(p):
     return q.view(r, k)
 
 
+def q_e5m2(p):
+    """fp8 e5m2 (bf8), no scale: fp16's exponent range with 2 mantissa bits"""
+    return p.float().to(torch.float8_e5m2).double()
+
+
+def q_mx(emax, mbits, vmax):
+    """OCP MX block format: one power-of-two scale per (row, 32-wide K tile) = 2^(floor(log2 max) - emax), elements
+    with `mbits` mantissa bits, subnormals below 2^(1 - bias) (bias 1 for e2m3, 7 for e4m3), saturating at vmax"""
+    emin = {2: 0, 8: -6}[emax]  # exponent of the smallest normal
+
+    def q(p):
+        r, k = p.shape
+        t = p.view(r, k // 32, 32)
+        mx = t.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+        s = torch.exp2(torch.floor(torch.log2(mx)) - emax)
+        v = t / s
+        e = torch.floor(torch.log2(v.abs().clamp_min(1e-300))).clamp_min(emin)
+        step = torch.exp2(e - mbits)
+        out = (torch.round(v / step) * step).clamp(-vmax, vmax) * s
+        return out.view(r, k)
+    return q
+
+
 def q_bits(nbits):
     def q(p):  # keep `nbits` significant bits (round to nearest), exponent unbounded: an upper bound for any n-bit format
         m, e = torch.frexp(p)
@@ -82,8 +105,11 @@ def main():
             print(f'head weights x{scale:g}: logits of head {head}: range {float(ref_l.max() - ref_l.min()):.2f}, '
                   f'std {float(ref_l.std()):.3f}', flush=True)
             real = F.linear
-            for name, q in (('fp16 planes (shipped)', q_identity), ('fp8 e4m3, per-tile scale', q_e4m3),
-                            ('8 significant bits (bf16-like)', q_bits(8)), ('6 significant bits', q_bits(6))):
+            variants = {'a': (('fp16 planes (shipped)', q_identity), ('fp8 e4m3, per-tile scale', q_e4m3),
+                              ('8 significant bits (bf16-like)', q_bits(8)), ('6 significant bits', q_bits(6))),
+                        'b': (('fp8 e5m2, no scale', q_e5m2), ('MXFP8 e4m3 (E8M0 block scale)', q_mx(8, 3, 448.0)),
+                              ('MXFP6 e2m3 (E8M0 block scale)', q_mx(2, 3, 7.5)))}[os.environ.get('T2H_EMU_SET', 'a')]
+            for name, q in variants:
                 F.linear = make_linear(q)
                 try:
                     h = R.transformer_hidden(idx, seg, tex, sd)

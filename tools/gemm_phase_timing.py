@@ -57,6 +57,10 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
     else:
         g.C_split = osp.data_ptr()
     g.epi_act = 1 if gelu else 0
+    if os.environ.get('T2H_TIMING_X8') == '1':  # x8 operands (random bytes: timing only) and, for fc1, x8 output
+        g.fmt, g.lo_mul = 1, 1.0 / 2048.0 / 64.0
+        if not res:
+            g.out_fmt, g.out_scale = (1, 4.0) if os.environ.get('T2H_TIMING_X8_OUT', '1') == '1' else (0, 0.0)
     ovf = torch.zeros(1, dtype=torch.int32, device='cuda')
     g.overflow_flag = ovf.data_ptr()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
