@@ -49,6 +49,7 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16 / bf16 MFMA dense (NOT the 2:1-sparse figure)
+FP8_MFMA_PEAK_TFLOPS = 5000.0   # MI355X_MICROARCH.md: fp8 dense through the block-scaled K = 64 / 128 instructions
 HBM_PEAK_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec
 MAX_CLOCK_GHZ = 2.4             # MI355X_MICROARCH.md: max clock, the clock the MFMA peaks are quoted at
 
@@ -313,6 +314,7 @@ def profile_side_data(kernel_label, config):
     out = {'traffic': None}
     if not kernel_label.startswith('gemm_split'):
         return out
+    out['profile_kernel'] = kernel_label
     want = kernel_src_digest()
     # (parsing at 32 images per GPU runs the sampler GEMMs at the pose configuration's shapes, M = 16384: its rows are
     # taken from that configuration's passes)
@@ -462,17 +464,23 @@ def gemm_roofline(prof, config):
     dom = max(prof.values(), key=lambda r: r['ms'])
     eq = dom['flops'] / (dom['ms'] * 1e-3) / 1e12  # fp32-equivalent 2*M*N*K per launch / time
     split = dom['kernel'].startswith('gemm_split')
-    # The split-precision kernel's algorithm is three fp16 x fp16 partial products per fp32 multiply
-    # on v_mfma_f32_32x32x16_f16: its matrix-core roofline is the dense 16-bit peak and its executed
-    # work 3 * 2*M*N*K (`frac`); the reference's own FLOP count against the same peak is `frac_useful`.
+    x8 = dom['kernel'] == 'gemm_split_kernel<x8>'
+    # The split-precision kernel's algorithm is three partial products per fp32 multiply: its executed work is
+    # 3 * 2*M*N*K (`frac`); the reference's own FLOP count against the fp16 peak is `frac_useful`.
+    #   <2xfp16>: all three on v_mfma_f32_32x32x16_f16 -> the dense 16-bit peak;
+    #   <x8>: hi*hi on that instruction, the two cross terms on v_mfma_scale_f32_32x32x64_f8f6f4 (8-bit operands, twice
+    #         the rate) -> the peak of THAT instruction mix: 3 / (1 / 2500 + 2 / 5000) = 3750 TFLOP/s
     mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split else (1.0, FP32_MFMA_PEAK_TFLOPS)
+    if x8:
+        peak = 3.0 / (1.0 / BF16_MFMA_PEAK_TFLOPS + 2.0 / FP8_MFMA_PEAK_TFLOPS)
     ach = eq * mult
     r = {
         'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': peak,
         'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-        'frac_basis': ('executed matrix instructions: 3 fp16 partial products per fp32 multiply'
+        'frac_basis': ('executed matrix instructions: fp16 hi*hi + both cross terms on the 8-bit instruction; peak = that mix (3750)'
+                       if x8 else 'executed matrix instructions: 3 fp16 partial products per fp32 multiply'
                        if split else 'fp32 matrix instructions = the reference FLOP count'),
-        'frac_useful': eq / peak,
+        'frac_useful': eq / (BF16_MFMA_PEAK_TFLOPS if split else peak),
         'fp32_equivalent_tflops': eq, 'frac_of_fp32_mfma_peak': eq / FP32_MFMA_PEAK_TFLOPS,
         'launches_sampled': dom['n'], 'avg_launch_us': 1000.0 * dom['ms'] / dom['n'],
         'avg_launch_us_basis': ('HIP events that receive the START and END of the kernel itself (hipExtLaunchKernelGGL, '
@@ -698,6 +706,7 @@ def side_config(name, run, steps, warmup, batch_per_gpu, world, dworld, dev, pro
 
 
 DTYPE_SPLIT = '2xf16-split operands (22 significant bits), f32 accumulate; exact-f32 number: exact_fp32_path'
+DTYPE_X8 = 'f16 hi plane + e4m3 cross-term planes, f32 accumulate (hidden err 4e-5, tokens exact); exact-f32: exact_fp32_path'
 COMPACT_LIMIT = 6000  # bytes; the driver keeps the last 8 KB of stdout and parses the last line
 
 
@@ -929,7 +938,8 @@ def main(argv=None):
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': ('stub' if stub else 'f32' if not split_on else DTYPE_SPLIT),
+        'dtype': ('stub' if stub else 'f32' if not split_on else
+                  DTYPE_X8 if getattr(getattr(model, 'sampler_fn', None), 'x8', False) else DTYPE_SPLIT),
         'dtype_detail': ('sampler Linears + attention and the decoder convolutions as 3 fp16 partial products per multiply '
                          'on v_mfma_f32_32x32x16_f16 -- fp32-class accuracy, see "parity" and "exact_fp32_path" for the '
                          'strictly-fp32 number; tokenizer, index-prediction UNet, parsing generator exact-f32 MFMA; GELU '

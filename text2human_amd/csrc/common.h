@@ -69,8 +69,12 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float wave_sum_dpp(float v) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) v += t2h_dpp_f(v, i);
-  const float r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-  const float r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  // (v_readlane_b32 moves BITS: the builtin's operand is an int)
+  const int x = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
   return (r0 + r1) + (r2 + r3);
 }
 

@@ -506,7 +506,7 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
                   't2h_gemm_split_time_next_launch')
             check(lib.t2h_gemm_split_probe_next_launch(_p(stamps)), 't2h_gemm_split_probe_next_launch')
             check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
-            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, k0, k1, 'kernel', cfg, stamps))
+            _prof['recs'].append((_split_label(g), 2.0 * M * N * K, k0, k1, 'kernel', cfg, stamps))
             return out if out is not None else out_split
         if phase == _prof['every'] // 2:
             # (e0, e1) are recorded on the stream around the launch and so run from the end of the previous
@@ -515,10 +515,16 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
             e0.record()
             check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
             e1.record()
-            _prof['recs'].append(('gemm_split_kernel<2xfp16>', 2.0 * M * N * K, e0, e1, 'stream', cfg, None))
+            _prof['recs'].append((_split_label(g), 2.0 * M * N * K, e0, e1, 'stream', cfg, None))
             return out if out is not None else out_split
     check(lib.t2h_gemm_split_f32(ctypes.byref(g), _stream()), 't2h_gemm_split_f32')
     return out if out is not None else out_split
+
+
+def _split_label(g):
+    """profile label of a split-GEMM launch: '<2xfp16>' = three fp16 partial products, '<x8>' = fp16 hi*hi + both
+    cross terms in one 8-bit instruction"""
+    return 'gemm_split_kernel<x8>' if g.fmt == 1 else 'gemm_split_kernel<2xfp16>'
 
 
 def split_overflow_async(reset=True):
