@@ -755,6 +755,8 @@ def compact_line(out):
         c['decode'] = _pick(rd, ('ms_per_image', 'hbm_frac', 'compute_frac_of_16bit_mfma_peak'))
     if 'exact_fp32_path' in out:
         c['exact_fp32_path'] = _pick(out['exact_fp32_path'], ('value', 'ms_per_step'))
+    if 'fp16_planes_path' in out:
+        c['fp16_planes_path'] = _pick(out['fp16_planes_path'], ('value', 'tokens_equal', 'images_u8_equal'))
     if 'parity' in out:
         c['parity'] = _pick(out['parity'], ('tokens_equal', 'token_mismatches', 'bot_indices_equal', 'img_max_abs',
                                             'img_u8_max_abs'))
@@ -1041,6 +1043,26 @@ def main(argv=None):
             'images_u8_equal': bool(int(diff.max()) == 0), 'img_u8_max_abs': int(diff.max()),
             'img_u8_frac_differing': float((diff != 0).float().mean()),
         }
+    if world == 1 and split_on and not args.no_exact_fp32 and getattr(model.sampler_fn, 'x8', False):
+        # the same step with the sampler's Linears on the two-fp16-plane operands (22 significant bits, the default
+        # until round 5): what the 8-bit cross-term planes buy on THIS box, and that the tokens are the same
+        net = model.sampler_fn
+        net.x8, net._graphs = False, {}
+        try:
+            run.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.exact_steps):
+                top_p, u8_p = run.step()
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t1) / args.exact_steps
+        finally:
+            net.x8, net._graphs = True, {}
+        out['fp16_planes_path'] = {'value': batch_per_gpu / dtp, 'unit': 'images/s', 'ms_per_step': 1000.0 * dtp,
+                                   'tokens_equal': bool(torch.equal(torch.stack(top_p), torch.stack(top))),
+                                   'images_u8_equal': bool(torch.equal(u8_p, u8)),
+                                   'note': 'T2H_X8=0: three fp16 partial products per multiply (22-bit operands) instead of '
+                                           f'fp16 hi*hi + 8-bit cross terms; 1 warm-up + {args.exact_steps} timed steps'}
     if world == 1 and not args.no_eager_gpu_baseline and args.config != 'pose':
         out['eager_gpu_baseline'] = eager_gpu_baseline(model, batch, sds, opt, args.eager_gpu_steps, dev)
     emit(out)

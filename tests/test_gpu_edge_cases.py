@@ -169,7 +169,7 @@ def test_emulated_torch_draws_fall_back_to_real_ones(model, monkeypatch):
     assert torch.equal(a, b) and gen.get_offset() == end_a
 
 
-def test_stale_overflow_flag_is_not_this_runs_and_decode_checks_its_own(opt, sds, model):
+def test_stale_overflow_flag_is_not_this_runs_and_decode_checks_its_own(opt, sds, model, monkeypatch):
     """The sticky split-overflow flag: a flag left by an earlier producer must not fail the next valid
     sampling run, and a decoder activation outside fp16's range must raise from decode_indices, naming
     the decode stage."""
@@ -183,6 +183,7 @@ def test_stale_overflow_flag_is_not_this_runs_and_decode_checks_its_own(opt, sds
     bad['top_post_quant_conv']['weight'] = sds['top_post_quant_conv']['weight'] * 1.0e12
     m2 = SampleFromParsingModel(opt, state_dicts=bad)
     m2.feed_data(synthetic.parsing_batch(1, seed=33))
+    monkeypatch.setenv('T2H_OVERFLOW_FALLBACK', '0')   # (default: the stage is re-run on the exact-fp32 kernels)
     with pytest.raises(engine.SplitOverflowError, match='VQGAN refine / decode.*T2H_SPLIT_CONV'):
         m2.decode_indices(top)
     assert not ops.split_overflow(reset=True)

@@ -97,18 +97,35 @@ def test_entry_point_writes_the_oracles_image_per_name(tmp_path, monkeypatch, po
         return top
 
     monkeypatch.setattr(sample_model.BaseSampleModel, 'sample_fn', spy)
+    written = {}   # name -> the uint8 image handed to the file writer (the dataset's names end in .jpg: the file
+    real_save = sample_model.save_u8_images   # itself is JPEG-compressed, as the reference's save_image would)
+
+    def save_spy(u8, save_dir, img_name):
+        for i, n in enumerate(img_name):
+            assert n not in written
+            written[n] = u8[i].cpu().numpy().copy()
+        return real_save(u8, save_dir, img_name)
+
+    monkeypatch.setattr(sample_model, 'save_u8_images', save_spy)
     sample_from_parsing.run(pose=pose, argv=['-opt', cfg, '--batch-size', str(BATCH)])
     monkeypatch.setattr(sample_model.BaseSampleModel, 'sample_fn', real)
+    monkeypatch.setattr(sample_model, 'save_u8_images', real_save)
     out = tmp_path / 'results' / name
     assert sorted(f for f in os.listdir(out) if not f.endswith('.log')) == sorted(names)  # one file per listed image
     assert len(recorded) == 2                             # 3 images in loader batches of 2
     want = _oracle_images(options.dict_to_nonedict(opt), sds, pose, recorded)
     assert sorted(want) == sorted(names)
+    import io
     for n in names:
+        # what was handed to the writer under this name = the oracle's image for this name (uint8, +-1 on < 0.5 %)
+        d = np.abs(written[n].astype(np.int16) - want[n].astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 5e-3, (n, int(d.max()), float((d != 0).mean()))
+        # and the file holds it, through the encoder its extension selects (PIL, like torchvision's save_image)
         img = np.array(Image.open(out / n))
         assert img.shape == (512, 256, 3) and img.dtype == np.uint8
-        d = np.abs(img.astype(np.int16) - want[n].astype(np.int16))
-        assert d.max() <= 1 and (d != 0).mean() < 5e-3, (n, int(d.max()), float((d != 0).mean()))
+        buf = io.BytesIO()
+        Image.fromarray(written[n]).save(buf, format=Image.registered_extensions()[os.path.splitext(n)[1].lower()])
+        assert np.array_equal(img, np.array(Image.open(io.BytesIO(buf.getvalue())))), n
     # the images of different names differ (a per-name mix-up cannot pass)
     assert not np.array_equal(want[names[0]], want[names[1]])
     assert os.path.exists(out / f'test_{name}.log')

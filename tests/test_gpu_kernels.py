@@ -552,3 +552,33 @@ def test_conv3x3_small_matches_fp64(n_img, H, W, cin, cout, pro):
     old = ops.conv3x3(rows, wp, n_img, H, W, cin, bias=b.to(DEV), pro=p)
     e_new, e_old = (got.cpu().double() - ref).abs().max().item(), (old.cpu().double() - ref).abs().max().item()
     assert e_new < 2e-5 + 3 * e_old, (e_new, e_old)
+
+
+@pytest.mark.parametrize('C', [96, 192, 384, 128])
+def test_groupnorm_finalize_from_epilogue_partials_any_channels_per_group(C):
+    """t2h_groupnorm_finalize_f32 (statistics from a producing conv's per-128-row partial sums) for channels-per-group
+    counts that do NOT divide 256 (cpg = 3, 6, 12: a checkpoint with ch = 96) as well as one that does, against
+    torch's GroupNorm folded into (scale, shift) tables.  (t2h_groupnorm_tables_f32, the pass over the tensor itself,
+    serves C / 4 | 256 only: ADVICE r04.)"""
+    n_img, hw, groups, eps = 2, 512, 32, 1e-6
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(n_img * hw, C, generator=g) * 1.7 + 0.4
+    gamma, beta = torch.randn(C, generator=g) * 0.3 + 1.0, torch.randn(C, generator=g) * 0.2
+    xc = x.view(n_img, hw // 128, 128, C).double()
+    part = torch.stack([xc.sum(2), (xc * xc).sum(2)], 2).contiguous()          # [n_img, chunks, 2, C] fp64
+    xd = x.to(DEV)
+    xd._t2h_gn_part = part.to(DEV)
+    scale, shift = ops.groupnorm_tables(xd, gamma.to(DEV), beta.to(DEV), n_img, hw, groups=groups, eps=eps)
+    xg = x.view(n_img, hw, groups, C // groups).double()
+    mean = xg.mean((1, 3), keepdim=True)
+    var = xg.var((1, 3), unbiased=False, keepdim=True)
+    rstd = (1.0 / torch.sqrt(var + eps)).expand(n_img, 1, groups, C // groups).reshape(n_img, C)
+    mean = mean.expand(n_img, 1, groups, C // groups).reshape(n_img, C)
+    want_scale = gamma.double() * rstd
+    want_shift = beta.double() - mean * want_scale
+    assert (scale.cpu().double() - want_scale).abs().max().item() < 1e-5
+    assert (shift.cpu().double() - want_shift).abs().max().item() < 1e-5
+    # applied: the normalised tensor equals torch's GroupNorm
+    ref = torch.nn.functional.group_norm(x.view(n_img, hw, C).permute(0, 2, 1), groups, gamma, beta, eps)
+    got = x.view(n_img, hw, C) * scale.cpu().unsqueeze(1) + shift.cpu().unsqueeze(1)
+    assert (got.permute(0, 2, 1) - ref).abs().max().item() < 2e-5

@@ -177,8 +177,10 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_finalize_kernel(const double* 
   __shared__ float g_stat[2];
   const int g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / groups;              // host: cpg <= 256
-  const int slices = GNF_THREADS / cpg;    // whole slices; when cpg does not divide 256 (a checkpoint with ch = 96:
-                                           // cpg = 3, 6, 12) the threads beyond slices * cpg stay idle and add zeros
+  const int slices = GNF_THREADS / cpg;    // whole slices; when cpg does not divide 256 (cpg = 3, 6, 12: ch = 96) the
+                                           // threads beyond slices * cpg stay idle and add zeros.  Tested for those
+                                           // counts (tests/test_gpu_kernels.py); the pass over the tensor itself,
+                                           // t2h_groupnorm_tables_f32 below, still serves C / 4 | 256 only
   const int ch = tid % cpg, sl = tid / cpg;
   const int per = (chunks + slices - 1) / slices;
   const int k0 = sl < slices ? sl * per : chunks, k1 = min(chunks, k0 + per);
