@@ -19,7 +19,9 @@ from ..ops import ACT_RELU
 
 logger = logging.getLogger('base')
 
-DECODE_CHUNK = 8  # images decoded per pass (activation footprint ~0.6 GB / image)
+# images decoded per pass: the decode's activations take ~0.6 GB / image at 512x256 (2.4 GB at 1024x512, where a pass
+# takes a quarter of this); T2H_DECODE_CHUNK overrides (a box with less free HBM, or larger passes on an idle 288 GB)
+DECODE_CHUNK = max(1, int(os.environ.get('T2H_DECODE_CHUNK', '8')))
 
 
 class BaseSampleModel():
