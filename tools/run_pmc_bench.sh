@@ -7,7 +7,7 @@
 set -u
 CFG=${1:-parsing}
 REPO=$GRAFT_REPO_ROOT
-ARGS="--config $CFG --steps 1 --warmup 1 --sample-steps 16 --no-cpu-baseline --no-exact-fp32 --no-other-configs --no-eager-leg"
+ARGS="--config $CFG --steps 1 --warmup 1 --sample-steps 16 --no-cpu-baseline --no-exact-fp32 --no-other-configs --no-eager-leg --no-eager-gpu-baseline"
 cd /tmp && export TMPDIR=/tmp
 export T2H_GRAPH=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
