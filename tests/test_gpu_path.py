@@ -230,3 +230,9 @@ def test_strict_checkpoint_validation(opt, sds):
     bad.pop('ln_f.weight')
     with pytest.raises(RuntimeError, match='Missing key'):
         weights.check_state_dict(bad, synthetic.module_schemas(opt)['sampler'], 'sampler')
+
+
+def test_graft_entry_smoke_runs():
+    """the driver's round-end smoke check (one small invocation of the hot path on cuda:0 against the oracle)"""
+    import __graft_entry__
+    __graft_entry__.smoke()
