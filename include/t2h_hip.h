@@ -103,6 +103,19 @@ int t2h_gemm_force_config(int cfg);
  * C, residual, bias stay fp32.  Replaces t2h_gemm_f32 at vqgan_arch.py:597-617,529-534,636-661,
  * 1000-1033,1136-1151 (opt-out: T2H_SPLIT_CONV=0). */
 int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
+/* The same 3x3 convolutions (3x3 'same', 3x3 after nearest-x2 upsample) with GroupNorm apply + swish + the fp16
+ * split folded into the operand staging: a workgroup owns a 16 x 16-pixel output tile x 128 output channels, stages
+ * the 18 x 18-pixel halo of 32 input channels ONCE in LDS (fp32 read, activated, split) and serves the nine taps from
+ * it -- no t2h_gn_apply_split_f32 pass (a full read + write of the normalised tensor), no per-tap re-read of the
+ * input.  Arguments as t2h_gemm_f32's conv mode: A = fp32 NHWC input (pixel stride lda >= Cin), pro_scale /
+ * pro_shift = the GroupNorm tables [n_img, pro_ld] with pro_act 1 (swish), or both NULL (plain convolution);
+ * B = split-row weights [N][9*Cin/32][2][32] as for t2h_conv_split_f32; K = 9*Cin, stride 1, pad 1, ups 0 / 1;
+ * Hout and Wout multiples of 16; bias / residual / gn_part_out as t2h_conv_split_f32 (a 128-pixel chunk of
+ * gn_part_out is half a tile).  K is summed [channel group][tap] (t2h_conv_split_f32: [tap][channel group]): the
+ * two agree to fp32 rounding, not bit for bit.  overflow_flag: the caller's sticky word (bit 0 is set when an
+ * activated value leaves fp16's range).  Replaces t2h_gn_apply_split_f32 + t2h_conv_split_f32 at
+ * vqgan_arch.py:597-617,529-534,1000-1033 where the grid fills the chip (opt-out: T2H_HALO_CONV=0). */
+int t2h_conv_halo_f32(const t2h_gemm_args* args, int32_t* overflow_flag, void* stream);
 /* 3x3 'same' convolution with 1..4 output channels (the decoders' conv_out, vqgan_arch.py:997,1026-1033) on
  * the vector ALU, exact fp32: out[pixel][co] = bias[co] + sum over taps, channels of
  * act(x * scale[img] + shift[img]) * w[co][tap][c] (scale NULL = no prologue; act 1 = swish), zero padding of

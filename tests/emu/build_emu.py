@@ -1,0 +1,50 @@
+"""Builds a HOST shared library out of a product kernel's source for tests/emu/hip_emu.h (test infrastructure).
+
+The kernel file and csrc/common.h are used as they are, minus what only a GPU can assemble: the
+`#include <hip/hip_runtime.h>` line and the inline `asm volatile(...)` statements of common.h's store helpers (which
+the emulated kernels do not call).  Output: tests/emu/_build/lib<name>_emu.so exporting the kernel file's extern "C"
+entry points with their product signatures."""
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'text2human_amd', 'csrc')
+OUT = os.path.join(HERE, '_build')
+
+
+def _host_clang():
+    for cand in ('/opt/rocm/lib/llvm/bin/clang++', shutil.which('amdclang++'), shutil.which('clang++')):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def available():
+    return _host_clang() is not None
+
+
+def build(kernel_file):
+    """-> path of the emulation library of csrc/<kernel_file> (rebuilt when a source changes)"""
+    name = kernel_file.replace('.hip', '')
+    common = open(os.path.join(CSRC, 'common.h')).read()
+    common = common.replace('#include <hip/hip_runtime.h>', '').replace('#pragma once', '')
+    common = common.replace('#include "../../include/t2h_hip.h"', f'#include "{os.path.join(ROOT, "include", "t2h_hip.h")}"')
+    common = common.replace('void t2h_set_error(const char* fmt, ...);', '')
+    common = re.sub(r'asm volatile\((?:.|\n)*?\);', ';', common)
+    kern = open(os.path.join(CSRC, kernel_file)).read().replace('#include "common.h"', '')
+    src = f'#include "{os.path.join(HERE, "hip_emu.h")}"\n' + common + '\n' + kern
+    dig = hashlib.sha256((src + open(os.path.join(HERE, 'hip_emu.h')).read()).encode()).hexdigest()[:16]
+    os.makedirs(OUT, exist_ok=True)
+    lib = os.path.join(OUT, f'lib{name}_emu_{dig}.so')
+    if os.path.exists(lib):
+        return lib
+    cpp = os.path.join(OUT, f'{name}_emu.cpp')
+    with open(cpp, 'w') as f:
+        f.write(src)
+    subprocess.run([_host_clang(), '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-everything', cpp, '-o', lib],
+                   check=True)
+    return lib

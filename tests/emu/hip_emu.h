@@ -1,0 +1,119 @@
+// Host emulation of ONE HIP workgroup at a time, for running a kernel's SOURCE on the CPU (test infrastructure:
+// tests/test_conv_halo_emulated.py; nothing in the product builds or loads this).
+//
+// A launch runs its workgroups one after another; the threads of a workgroup are real OS threads, __syncthreads() is
+// a pthread barrier, __shared__ storage is a function-local static (one workgroup alive at a time), and the matrix
+// instruction is a wave-collective: 64 threads deposit their operand registers, meet at the wave's barrier, and every
+// lane computes the 16 accumulator elements it owns.  Operand / accumulator lane layout of
+// v_mfma_f32_32x32x16_f16 as the product kernels use it (conv_split.hip, gemm_split.hip -- parity-tested on the GPU):
+//   A: lane l holds row (l & 31), k = 8 (l >> 5) .. + 7;   B: lane l holds column (l & 31), the same k;
+//   D: lane l holds column (l & 31), rows (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 0 .. 15.
+// What it checks: index algebra, LDS layout, buffer rotation, borders, the epilogue's row mapping -- with truly
+// concurrent threads.  What it cannot check: timing, bank conflicts, the hardware's instruction semantics beyond the
+// ones restated here.
+#pragma once
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+static thread_local dim3 threadIdx, blockIdx, blockDim;
+static thread_local int emu_tid;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__
+using std::max;
+using std::min;
+typedef void* hipStream_t;
+typedef int hipError_t;
+constexpr int hipSuccess = 0;
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+
+static pthread_barrier_t emu_block_bar;
+static inline void __syncthreads() { pthread_barrier_wait(&emu_block_bar); }
+static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+
+// builtins of the product's helpers that the emulated kernels do not execute (common.h parses them)
+#define __builtin_amdgcn_update_dpp(old, x, ...) (x)
+#define __builtin_amdgcn_readlane(x, i) (x)
+#define __shfl_xor(v, o, w) (v)
+#define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, hi) (w)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_sched_barrier(x)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c)
+
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+struct emu_wave {
+  _Float16 a[64][8], b[64][8];
+  pthread_barrier_t bar;
+};
+static emu_wave emu_waves[16];
+
+static inline emu_f32x16 emu_mfma_f32_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c) {
+  const int lane = emu_tid & 63;
+  emu_wave& W = emu_waves[emu_tid >> 6];
+  for (int e = 0; e < 8; ++e) {
+    W.a[lane][e] = a[e];
+    W.b[lane][e] = b[e];
+  }
+  pthread_barrier_wait(&W.bar);
+  const int j = lane & 31, hh = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    float s = 0.f;
+    for (int k = 0; k < 16; ++k) s += (float)W.a[i + 32 * (k >> 3)][k & 7] * (float)W.b[j + 32 * (k >> 3)][k & 7];
+    c[r] += s;
+  }
+  pthread_barrier_wait(&W.bar);
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_f16(a, b, c)
+
+template <typename K, typename... A>
+static void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
+  for (unsigned b = 0; b < grid.x; ++b) {
+    pthread_barrier_init(&emu_block_bar, nullptr, block.x);
+    for (unsigned w = 0; w < (block.x + 63) / 64; ++w) pthread_barrier_init(&emu_waves[w].bar, nullptr, 64);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < block.x; ++t)
+      th.emplace_back([=] {
+        threadIdx = dim3(t);
+        blockIdx = dim3(b);
+        blockDim = block;
+        emu_tid = (int)t;
+        kernel(args...);
+      });
+    for (auto& x : th) x.join();
+    pthread_barrier_destroy(&emu_block_bar);
+    for (unsigned w = 0; w < (block.x + 63) / 64; ++w) pthread_barrier_destroy(&emu_waves[w].bar);
+  }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
+
+static char emu_err[512];
+#include <stdarg.h>
+void t2h_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(emu_err, sizeof emu_err, fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* emu_last_error(void) { return emu_err; }

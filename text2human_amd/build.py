@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libt2h_hip.so')
 OBJ_DIR = os.path.join(HERE, 'csrc', 'build')
-SOURCES = ['api.hip', 'gemm.hip', 'gemm_split.hip', 'conv_split.hip', 'conv_small.hip', 'attention.hip', 'spatial_attn.hip', 'norm.hip', 'sampler.hip',
+SOURCES = ['api.hip', 'gemm.hip', 'gemm_split.hip', 'conv_split.hip', 'conv_halo.hip', 'conv_small.hip', 'attention.hip', 'spatial_attn.hip', 'norm.hip', 'sampler.hip',
            'vq.hip', 'misc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment']
 

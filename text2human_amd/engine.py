@@ -53,6 +53,12 @@ class VQGANStack:
         hw_out = h * w * (4 if mode == 'up' else 1)
         ws = self._ws(f'{conv}.w', hw_out, mode)
         pro = self._gn(x, norm, n_img, h * w) if norm is not None else None
+        if ws is not None and ops.conv_halo_ok(n_img, h * (2 if mode == 'up' else 1), w * (2 if mode == 'up' else 1),
+                                               cin, cout, mode):
+            # large levels: GroupNorm apply + swish + split happen while the 18 x 18-pixel halo of a 16 x 16 tile is
+            # staged (csrc/conv_halo.hip) -- no elementwise pass, every input pixel read 1.27x instead of 9x
+            return ops.conv_halo(x, ws, n_img, h, w, cin, cout, bias=P[f'{conv}.b'], residual=residual, mode=mode,
+                                 pro=pro, gn_stats=cout <= 1024)
         if ws is not None:
             xs = ops.gn_apply_split(x, *(pro or (None, None)), rows_per_img=h * w,
                                     act=PRO_SWISH if pro is not None else PRO_NONE)

@@ -5,6 +5,7 @@ function here checks dtype / device / contiguity, takes raw device pointers and
 the current HIP stream, and calls into libt2h_hip.so.
 """
 import ctypes
+import os
 
 import torch
 
@@ -270,6 +271,69 @@ def conv_split(xs, w_split, n_img, hin, win, cin, cout, taps=9, out=None, bias=N
     _launch_conv_split(g, 2.0 * M * cout * taps * cin)
     if part is not None:
         out._t2h_gn_part = part  # groupnorm_tables(out, ...) then only reduces these partials
+    return out
+
+
+def conv_halo_ok(n_img, hout, wout, cin, cout, mode='same'):
+    """Shapes t2h_conv_halo_f32 serves AND is meant for: 3x3 'same' / nearest-x2 convolutions whose 16 x 16-pixel
+    tiles x 128-channel column tiles give every CU a workgroup (the decoders' large levels); the small levels keep
+    the 128-pixel tiles of t2h_conv_split_f32.  T2H_HALO_CONV=0 switches it off."""
+    knob = os.environ.get('T2H_HALO_CONV', '1')
+    if knob == '0':
+        return False
+    served = mode in ('same', 'up') and hout % 16 == 0 and wout % 16 == 0 and cin % 32 == 0 and cout % 8 == 0
+    # (T2H_HALO_CONV=2: wherever the kernel serves the shape, whatever the grid -- tests)
+    return served and (knob == '2' or n_img * (hout // 16) * (wout // 16) * ((cout + 127) // 128) >= 256)
+
+
+def conv_halo(x, w_split, n_img, hin, win, cin, cout, out=None, bias=None, residual=None, mode='same', pro=None,
+              gn_stats=False):
+    """3x3 convolution (mode 'same', or 'up': after nearest x2) of fp32 NHWC rows x [n_img*hin*win, >= cin] with
+    split-row weights w_split [cout, 9*cin/32, 2, 32]; pro = (scale, shift) [n_img, C] GroupNorm tables applied with
+    swish while the operand is staged (None: plain convolution).  fp32 rows out [M, cout]; gn_stats as conv_split."""
+    _chk_f32(x, out, bias, residual)
+    assert mode in ('same', 'up')
+    ups = 1 if mode == 'up' else 0
+    hout, wout = hin << ups, win << ups
+    M = n_img * hout * wout
+    assert x.shape[0] == n_img * hin * win and x.shape[1] >= cin and w_split.numel() == cout * 9 * cin * 2, \
+        (tuple(x.shape), tuple(w_split.shape), n_img, hin, win, cin, cout)
+    if out is None:
+        out = torch.empty((M, cout), device=x.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.A, g.B, g.C = x.data_ptr(), w_split.data_ptr(), out.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.residual = residual.data_ptr() if residual is not None else None
+    g.M, g.N, g.K = M, cout, 9 * cin
+    g.lda, g.ldb, g.ldc = _rows(x), 0, _rows(out)
+    g.ldr = _rows(residual) if residual is not None else 0
+    g.a_mode, g.epi_act, g.alpha, g.res_pre = 1, ACT_NONE, 1.0, 0
+    g.Hin, g.Win, g.Cin, g.Hout, g.Wout = hin, win, cin, hout, wout
+    g.stride, g.pad, g.ups, g.batch = 1, 1, ups, 1
+    if pro is not None:
+        sc, sh = pro
+        _chk_f32(sc, sh)
+        g.pro_scale, g.pro_shift, g.pro_ld, g.pro_act = sc.data_ptr(), sh.data_ptr(), sc.shape[1], PRO_SWISH
+    part = None
+    if gn_stats:
+        part = torch.empty((n_img, hout * wout // 128, 2, cout), device=x.device, dtype=torch.float64)
+        g.gn_part_out = part.data_ptr()
+    lib = _lib.load()
+    flops = 2.0 * M * cout * 9 * cin
+    if _prof is not None:
+        _prof['count'] += 1
+        if _prof['count'] % _prof['every'] == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.t2h_conv_halo_f32(ctypes.byref(g), overflow_flag(), _stream()), 't2h_conv_halo_f32')
+            e1.record()
+            _prof['recs'].append(('conv_halo_kernel<2xfp16>', flops, e0, e1))
+            if part is not None:
+                out._t2h_gn_part = part
+            return out
+    check(lib.t2h_conv_halo_f32(ctypes.byref(g), overflow_flag(), _stream()), 't2h_conv_halo_f32')
+    if part is not None:
+        out._t2h_gn_part = part
     return out
 
 
