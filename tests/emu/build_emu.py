@@ -36,6 +36,21 @@ def build(kernel_file):
     common = common.replace('void t2h_set_error(const char* fmt, ...);', '')
     common = re.sub(r'asm volatile\((?:.|\n)*?\);', ';', common)
     kern = open(os.path.join(CSRC, kernel_file)).read().replace('#include "common.h"', '')
+    # the kernel file's own inline-assembly idioms, restated for the host: a 16-byte global load becomes a copy
+    # (synchronous here), an LDS-DMA request a copy into the emulated LDS (lane-linear, 16 bytes per lane), a counted
+    # wait and an opaque register copy become nothing
+    rules = [
+        (r'asm volatile\("global_load_dwordx4 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "s"\((\w+)\) : "memory"\);',
+         r'memcpy(&\1, \3 + \2, 16);'),
+        (r'asm volatile\("s_mov_b32 %0, m0[^;]*global_load_lds_dwordx4[^;]*: "=&s"\(keep\) : "v"\((\w+)\), "s"\((\w+)\), "s"\(dst\) : "memory"\);',
+         r'memcpy(lds_dst + (emu_tid & 63) * 16, \2 + \1, 16);'),
+        (r'asm volatile\("s_waitcnt vmcnt\(%1\)" : "\+v"\(\w+\) : "n"\(N\)\);', ';'),
+        (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ';'),
+        (r'asm volatile\("" : "\+v"\(\w+\)\);', ';'),
+    ]
+    for pat, rep in rules:
+        kern = re.sub(pat, rep, kern)
+    assert 'asm volatile' not in kern, 'an inline-assembly idiom of the kernel file has no host restatement'
     src = f'#include "{os.path.join(HERE, "hip_emu.h")}"\n' + common + '\n' + kern
     dig = hashlib.sha256((src + open(os.path.join(HERE, 'hip_emu.h')).read()).encode()).hexdigest()[:16]
     os.makedirs(OUT, exist_ok=True)

@@ -51,21 +51,36 @@ static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATO
 // builtins of the product's helpers that the emulated kernels do not execute (common.h parses them)
 #define __builtin_amdgcn_update_dpp(old, x, ...) (x)
 #define __builtin_amdgcn_readlane(x, i) (x)
-#define __shfl_xor(v, o, w) (v)
 #define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, hi) (w)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_readfirstlane(x) (x)
-#define __builtin_amdgcn_sched_barrier(x)
-#define __builtin_amdgcn_sched_group_barrier(a, b, c)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
 struct emu_wave {
   _Float16 a[64][8], b[64][8];
+  uint64_t shfl[64];
   pthread_barrier_t bar;
 };
 static emu_wave emu_waves[16];
+
+// wave-collective lane exchange (every lane of the wave must call it)
+template <typename T>
+static inline T emu_shfl_xor(T v, int mask) {
+  static_assert(sizeof(T) <= 8, "4- and 8-byte values");
+  emu_wave& W = emu_waves[emu_tid >> 6];
+  const int lane = emu_tid & 63;
+  memcpy(&W.shfl[lane], &v, sizeof(T));
+  pthread_barrier_wait(&W.bar);
+  T r;
+  memcpy(&r, &W.shfl[lane ^ mask], sizeof(T));
+  pthread_barrier_wait(&W.bar);
+  return r;
+}
+#define __shfl_xor(v, o, w) emu_shfl_xor(v, o)
 
 static inline emu_f32x16 emu_mfma_f32_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c) {
   const int lane = emu_tid & 63;

@@ -15,6 +15,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
+@pytest.fixture(params=[1, 0], ids=['two-fragment-sets', 'first-version'])
+def variant(request):
+    """both main loops of the kernel (the library's default is 1)"""
+    lib = _lib.load()
+    lib.t2h_conv_halo_force_variant(request.param)
+    yield request.param
+    lib.t2h_conv_halo_force_variant(1)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
@@ -48,7 +57,7 @@ def describe_errors(got, ref, n_img, ho, wo):
                                                (128, 96, 16, 48, 3),     # N not a multiple of the column tile
                                                (96, 256, 32, 32, 1),     # three groups (odd), two column tiles
                                                (256, 128, 16, 32, 2)])   # eight groups
-def test_conv_halo_vs_fp64_and_vs_the_two_kernel_path(mode, cin, cout, h, w, n_img):
+def test_conv_halo_vs_fp64_and_vs_the_two_kernel_path(mode, cin, cout, h, w, n_img, variant):
     x = rnd(n_img, cin, h, w, seed=13)
     wt, b = rnd(cout, cin, 3, 3, seed=14, scale=0.1), rnd(cout, seed=15)
     sc, sh = rnd(n_img, cin, seed=16) * 0.3 + 1, rnd(n_img, cin, seed=17) * 0.3

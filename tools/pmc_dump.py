@@ -1,7 +1,9 @@
 """Dump per-kernel averages of every counter found in rocprofv3 --pmc result DBs.
 
     python tools/pmc_dump.py gpurun_out/pmc2/*/p_results.db > gpurun_out/pmc2/summary.txt
+    PMC_DUMP_FILTER=conv,gn_apply python tools/pmc_dump.py ...     (kernel-name substrings; default gemm,mha)
 """
+import os
 import re
 import sqlite3
 import sys
@@ -10,7 +12,7 @@ import sys
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
-    return name[:44]
+    return name[:60]
 
 
 def main(paths):
@@ -25,7 +27,7 @@ def main(paths):
         except Exception as e:  # a pass whose counter is not available on this box
             print(f'# {db}: {e}')
     for (k, grid), cs in sorted(rows.items()):
-        if 'gemm' not in k and 'mha' not in k:
+        if not any(f in k for f in os.environ.get('PMC_DUMP_FILTER', 'gemm,mha').split(',')):
             continue
         print(f'{k} grid={grid}')
         for cn, (n, avg, us) in sorted(cs.items()):
