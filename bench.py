@@ -668,8 +668,9 @@ def stage_view(stage_ms, b, sample_steps, upscale, stats):
             compute_frac_of_fp32_mfma_peak=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             compute_frac_of_16bit_mfma_peak=(3.0 if split_conv else 1.0) * fl / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
             algorithmic_hbm_bytes=by, hbm_frac=by / t / (HBM_PEAK_TBS * 1e12),
-            convs=('2xfp16-split MFMA, three products (t2h_conv_split_f32): executed = 3 x the reference FLOPs'
-                   if split_conv else 'exact-fp32 MFMA'),
+            convs=('2xfp16-split MFMA, three products: executed = 3 x the reference FLOPs; the large levels by '
+                   't2h_conv_halo_f32 (GroupNorm apply + swish + split folded into the halo staging), the small ones by '
+                   't2h_gn_apply_split_f32 + t2h_conv_split_f32' if split_conv else 'exact-fp32 MFMA'),
             note='SURVEY.md 8(d) algorithmic FLOPs / bytes (flash-style attention, fused norms).  The stage '
                  'is matrix-bound: at 100% of the fp32 MFMA peak its HBM fraction would be 6.5%, at 100% of '
                  'the three-product fp16 rate 35%')

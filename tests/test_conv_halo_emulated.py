@@ -118,3 +118,18 @@ def test_emulated_entry_point_rejects_what_the_kernel_does_not_serve(lib):
     g.Hin, g.Win, g.Hout, g.Wout, g.stride, g.pad = 24, 16, 24, 16, 1, 1
     assert lib.t2h_conv_halo_f32(ctypes.byref(g), ovf.data_ptr(), None) != 0
     assert b'multiples of 16' in lib.emu_last_error()
+
+
+def test_kernel_choice_is_a_function_of_the_image_geometry_only(monkeypatch):
+    """ops.conv_halo_ok decides between two kernels that sum K in different orders: it must not look at the batch."""
+    monkeypatch.delenv('T2H_HALO_CONV', raising=False)
+    for shape in ((512, 256, 128, 128), (256, 128, 256, 128), (128, 64, 256, 256), (64, 32, 512, 512),
+                  (64, 32, 256, 256), (32, 16, 512, 512), (1024, 512, 128, 128)):
+        assert len({ops.conv_halo_ok(n, *shape) for n in (1, 2, 3, 4, 8, 32)}) == 1, shape
+    assert ops.conv_halo_ok(1, 512, 256, 128, 128) and ops.conv_halo_ok(1, 64, 32, 512, 512)
+    assert not ops.conv_halo_ok(8, 64, 32, 256, 256) and not ops.conv_halo_ok(8, 32, 16, 512, 512)
+    assert not ops.conv_halo_ok(8, 24, 16, 32, 128) and not ops.conv_halo_ok(8, 512, 256, 128, 128, 'down')
+    monkeypatch.setenv('T2H_HALO_CONV', '0')
+    assert not ops.conv_halo_ok(8, 512, 256, 128, 128)
+    monkeypatch.setenv('T2H_HALO_CONV', '2')
+    assert ops.conv_halo_ok(1, 32, 16, 512, 512)

@@ -121,6 +121,9 @@ def test_conv_halo_overflow_word_and_rejections():
         ops.conv_halo(rnd(24 * 16, cin, seed=7).to(DEV), ws, 1, 24, 16, cin, cout)
     assert not ops.conv_halo_ok(8, 24, 16, 32, 128) and not ops.conv_halo_ok(8, 512, 256, 128, 128, 'down')
     assert ops.conv_halo_ok(8, 512, 256, 128, 128) and not ops.conv_halo_ok(1, 32, 16, 512, 512)
+    # the choice between the two kernels never depends on the batch (an image must not depend on its neighbours)
+    for shape in ((512, 256, 128, 128), (128, 64, 256, 256), (64, 32, 512, 512), (64, 32, 256, 256), (32, 16, 512, 512)):
+        assert len({ops.conv_halo_ok(n, *shape) for n in (1, 2, 3, 8, 32)}) == 1, shape
 
 
 @pytest.mark.parametrize('knob', ['2', '0'])

@@ -276,14 +276,17 @@ def conv_split(xs, w_split, n_img, hin, win, cin, cout, taps=9, out=None, bias=N
 
 def conv_halo_ok(n_img, hout, wout, cin, cout, mode='same'):
     """Shapes t2h_conv_halo_f32 serves AND is meant for: 3x3 'same' / nearest-x2 convolutions whose 16 x 16-pixel
-    tiles x 128-channel column tiles give every CU a workgroup (the decoders' large levels); the small levels keep
-    the 128-pixel tiles of t2h_conv_split_f32.  T2H_HALO_CONV=0 switches it off."""
+    tiles x 128-channel column tiles give at least 32 workgroups PER IMAGE (a chunk of 8 images then gives every CU
+    one: the decoders' levels from 64 x 32 / 512 channels up); the small levels keep the 128-pixel tiles of
+    t2h_conv_split_f32.  Deliberately NOT a function of n_img: the two kernels sum K in different orders, and an
+    image must not depend on how many neighbours it is decoded with (tests/test_gpu_edge_cases.py:
+    test_decode_chunk_boundary_is_invisible compares bit for bit).  T2H_HALO_CONV=0 switches the kernel off, =2 uses
+    it wherever it serves the shape (tests)."""
     knob = os.environ.get('T2H_HALO_CONV', '1')
     if knob == '0':
         return False
-    served = mode in ('same', 'up') and hout % 16 == 0 and wout % 16 == 0 and cin % 32 == 0 and cout % 8 == 0
-    # (T2H_HALO_CONV=2: wherever the kernel serves the shape, whatever the grid -- tests)
-    return served and (knob == '2' or n_img * (hout // 16) * (wout // 16) * ((cout + 127) // 128) >= 256)
+    served = mode in ('same', 'up') and hout % 16 == 0 and wout % 16 == 0 and cin % 32 == 0 and cout % 8 == 0 and cin <= 512
+    return served and (knob == '2' or (hout // 16) * (wout // 16) * ((cout + 127) // 128) >= 32)
 
 
 def conv_halo(x, w_split, n_img, hin, win, cin, cout, out=None, bias=None, residual=None, mode='same', pro=None,
