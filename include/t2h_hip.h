@@ -114,9 +114,11 @@ int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
  * gn_part_out is half a tile).  K is summed [channel group][tap] (t2h_conv_split_f32: [tap][channel group]): the
  * two agree to fp32 rounding, not bit for bit.  overflow_flag: the caller's sticky word (bit 0 is set when an
  * activated value leaves fp16's range).  Replaces t2h_gn_apply_split_f32 + t2h_conv_split_f32 at
- * vqgan_arch.py:597-617,529-534,1000-1033 where the grid fills the chip (opt-out: T2H_HALO_CONV=0). */
+ * vqgan_arch.py:597-617,529-534,1000-1033 at the decoders' large levels (the caller chooses by the image geometry,
+ * never by the batch: ops.conv_halo_ok; opt-out: T2H_HALO_CONV=0).  Default kernel: weight tiles by LDS-DMA, Cin <= 512
+ * with tables, an image and the weights < 2 GiB each. */
 int t2h_conv_halo_f32(const t2h_gemm_args* args, int32_t* overflow_flag, void* stream);
-int t2h_conv_halo_force_variant(int v); /* tuning / tests (thread-local): 1 = two whole fragment sets, tables in LDS (default); 0 = first version; returns the old value */
+int t2h_conv_halo_force_variant(int v); /* tuning / tests (thread-local): 1 = LDS-DMA weight tiles, two fragment sets, staged conversion (default); 0 = the first, register-staged kernel; returns the old value */
 /* 3x3 'same' convolution with 1..4 output channels (the decoders' conv_out, vqgan_arch.py:997,1026-1033) on
  * the vector ALU, exact fp32: out[pixel][co] = bias[co] + sum over taps, channels of
  * act(x * scale[img] + shift[img]) * w[co][tap][c] (scale NULL = no prologue; act 1 = swish), zero padding of

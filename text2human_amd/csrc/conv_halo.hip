@@ -18,12 +18,15 @@
 //    nine taps are then nine K tiles whose A fragments are the SAME LDS image read at a shifted
 //    pixel: a(.) and the split are computed 1.27x per element (the halo overlap) instead of 9 x
 //    Cout / 128 times (the first conv_split version, VALU-bound) or in a pass of their own.
-//  * Weights stream as in conv_split.hip: one [128 rows][32 channels of one tap] tile per K tile,
-//    global -> registers -> LDS, double buffered, requested one K tile ahead.
-//  * The halo of the NEXT channel group is requested, converted and written to the second halo buffer
-//    while the nine taps of the current group are multiplied: three 8-channel pieces per thread,
-//    requested two taps before they are converted; the two waves of a SIMD convert in alternate taps, at the top of
-//    the tap, so that one wave's conversion runs in the shadow of the other's matrix instructions.
+//  * Weights stream one [128 rows][32 channels of one tap] tile per K tile, and the halo of the NEXT channel
+//    group is requested, converted and written to the second halo buffer while the nine taps of the current
+//    group are multiplied (three 8-channel pieces per thread).  HOW is what the two kernels of this file differ
+//    in: kernel 1 (the first version, kept as the A/B reference) moves the weight tiles through registers and
+//    converts a whole piece in one block; kernel 2 (the default) uses LDS-DMA for the weights, keeps two whole
+//    fragment sets in flight and cuts the conversion into stages behind the matrix instructions -- see the
+//    banners below and profiles/r05_conv_halo_phase_timing.log for the measurements that led there
+//    (level-0 layer of the decoder, 8 x 512 x 256 pixels, 128 -> 128 channels: 1427 us for the two-kernel
+//    path, 1008 us kernel 1, 892 us kernel 2).
 //  * K order is [channel group][tap] (conv_split: [tap][channel group]): same products, a different
 //    fp32 summation order.  Three partial products per k16 step (hi.hi, hi.lo, lo.hi), two fp32
 //    accumulator sets merged in the epilogue -- conv_split.hip's arithmetic unchanged.
