@@ -1,8 +1,8 @@
 """Builds a HOST shared library out of a product kernel's source for tests/emu/hip_emu.h (test infrastructure).
 
 The kernel file and csrc/common.h are used as they are, minus what only a GPU can assemble: the
-`#include <hip/hip_runtime.h>` line and the inline `asm volatile(...)` statements of common.h's store helpers (which
-the emulated kernels do not call).  Output: tests/emu/_build/lib<name>_emu.so exporting the kernel file's extern "C"
+`#include <hip/hip_runtime.h>` line, and with their few inline-assembly idioms (16-byte loads / write-through stores,
+LDS-DMA requests, counted waits) replaced by what they mean (`rules` below; an idiom without a rule fails the build).  Output: tests/emu/_build/lib<name>_emu.so exporting the kernel file's extern "C"
 entry points with their product signatures."""
 import hashlib
 import os
@@ -34,14 +34,19 @@ def build(kernel_file):
     common = common.replace('#include <hip/hip_runtime.h>', '').replace('#pragma once', '')
     common = common.replace('#include "../../include/t2h_hip.h"', f'#include "{os.path.join(ROOT, "include", "t2h_hip.h")}"')
     common = common.replace('void t2h_set_error(const char* fmt, ...);', '')
-    common = re.sub(r'asm volatile\((?:.|\n)*?\);', ';', common)
     kern = open(os.path.join(CSRC, kernel_file)).read().replace('#include "common.h"', '')
-    # the kernel file's own inline-assembly idioms, restated for the host: a 16-byte global load becomes a copy
-    # (synchronous here), an LDS-DMA request a copy into the emulated LDS (lane-linear, 16 bytes per lane), a counted
-    # wait and an opaque register copy become nothing
+    # the inline-assembly idioms of common.h and of the kernel files, restated for the host: a 16-byte global load /
+    # write-through store becomes a copy (synchronous here), an LDS-DMA request a copy into the emulated LDS
+    # (lane-linear, 16 bytes per lane), a counted wait and an opaque register copy become nothing
     rules = [
         (r'asm volatile\("global_load_dwordx4 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "s"\((\w+)\) : "memory"\);',
          r'memcpy(&\1, \3 + \2, 16);'),
+        (r'asm volatile\("global_load_dwordx4 %0, %1, off" : "=v"\((\w+)\) : "v"\((\w+)\) : "memory"\);',
+         r'memcpy(&\1, \2, 16);'),
+        (r'asm volatile\("global_store_dwordx4 %0, %1, off sc1\\n\\ts_nop 1" ::"v"\((\w+)\), "v"\((\w+)\) : "memory"\);',
+         r'memcpy(\1, &\2, 16);'),
+        (r'asm volatile\("global_store_dwordx2 %0, %1, off sc1\\n\\ts_nop 0" ::"v"\((\w+)\), "v"\((\w+)\) : "memory"\);',
+         r'memcpy(\1, &\2, 8);'),
         (r'asm volatile\("s_mov_b32 %0, m0[^;]*global_load_lds_dwordx4[^;]*: "=&s"\(keep\) : "v"\((\w+)\), "s"\((\w+)\), "s"\(dst\) : "memory"\);',
          r'memcpy(lds_dst + (emu_tid & 63) * 16, \2 + \1, 16);'),
         (r'asm volatile\("s_waitcnt vmcnt\(%1\)" : "\+v"\(\w+\) : "n"\(N\)\);', ';'),
@@ -49,14 +54,19 @@ def build(kernel_file):
         (r'asm volatile\("" : "\+v"\(\w+\)\);', ';'),
     ]
     for pat, rep in rules:
+        common = re.sub(pat, rep, common)
         kern = re.sub(pat, rep, kern)
-    assert 'asm volatile' not in kern, 'an inline-assembly idiom of the kernel file has no host restatement'
+    for name_, text in (('common.h', common), (kernel_file, kern)):
+        assert 'asm volatile' not in text, f'an inline-assembly idiom of {name_} has no host restatement'
     src = f'#include "{os.path.join(HERE, "hip_emu.h")}"\n' + common + '\n' + kern
     dig = hashlib.sha256((src + open(os.path.join(HERE, 'hip_emu.h')).read()).encode()).hexdigest()[:16]
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, f'lib{name}_emu_{dig}.so')
     if os.path.exists(lib):
         return lib
+    for old in os.listdir(OUT):  # earlier builds of this kernel file
+        if old.startswith(f'lib{name}_emu_') and old.endswith('.so'):
+            os.remove(os.path.join(OUT, old))
     cpp = os.path.join(OUT, f'{name}_emu.cpp')
     with open(cpp, 'w') as f:
         f.write(src)

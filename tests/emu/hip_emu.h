@@ -15,6 +15,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -49,8 +50,6 @@ static inline void __syncthreads() { pthread_barrier_wait(&emu_block_bar); }
 static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 
 // builtins of the product's helpers that the emulated kernels do not execute (common.h parses them)
-#define __builtin_amdgcn_update_dpp(old, x, ...) (x)
-#define __builtin_amdgcn_readlane(x, i) (x)
 #define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, hi) (w)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
@@ -81,6 +80,30 @@ static inline T emu_shfl_xor(T v, int mask) {
   return r;
 }
 #define __shfl_xor(v, o, w) emu_shfl_xor(v, o)
+// the DPP controls the product's wave reductions use (common.h: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror,
+// row_mirror, all lanes enabled) and v_readlane_b32, as lane exchanges
+static inline int emu_lane_from(int v, int src) {
+  emu_wave& W = emu_waves[emu_tid >> 6];
+  const int lane = emu_tid & 63;
+  memcpy(&W.shfl[lane], &v, sizeof v);
+  pthread_barrier_wait(&W.bar);
+  int r;
+  memcpy(&r, &W.shfl[src], sizeof r);
+  pthread_barrier_wait(&W.bar);
+  return r;
+}
+static inline int emu_update_dpp(int x, int ctrl) {
+  const int lane = emu_tid & 63;
+  int src = lane;
+  if (ctrl == 0xB1) src = lane ^ 1;
+  else if (ctrl == 0x4E) src = lane ^ 2;
+  else if (ctrl == 0x141) src = (lane & ~7) | (7 - (lane & 7));
+  else if (ctrl == 0x140) src = (lane & ~15) | (15 - (lane & 15));
+  else abort();
+  return emu_lane_from(x, src);
+}
+#define __builtin_amdgcn_update_dpp(old, x, ctrl, rm, bm, bc) emu_update_dpp(x, ctrl)
+#define __builtin_amdgcn_readlane(x, i) emu_lane_from(x, i)
 
 static inline emu_f32x16 emu_mfma_f32_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c) {
   const int lane = emu_tid & 63;
@@ -104,22 +127,25 @@ static inline emu_f32x16 emu_mfma_f32_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu
 
 template <typename K, typename... A>
 static void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
-  for (unsigned b = 0; b < grid.x; ++b) {
-    pthread_barrier_init(&emu_block_bar, nullptr, block.x);
-    for (unsigned w = 0; w < (block.x + 63) / 64; ++w) pthread_barrier_init(&emu_waves[w].bar, nullptr, 64);
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < block.x; ++t)
-      th.emplace_back([=] {
-        threadIdx = dim3(t);
-        blockIdx = dim3(b);
-        blockDim = block;
-        emu_tid = (int)t;
-        kernel(args...);
-      });
-    for (auto& x : th) x.join();
-    pthread_barrier_destroy(&emu_block_bar);
-    for (unsigned w = 0; w < (block.x + 63) / 64; ++w) pthread_barrier_destroy(&emu_waves[w].bar);
-  }
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned b = 0; b < grid.x; ++b) {
+        pthread_barrier_init(&emu_block_bar, nullptr, block.x);
+        for (unsigned w = 0; w < (block.x + 63) / 64; ++w)
+          pthread_barrier_init(&emu_waves[w].bar, nullptr, std::min(64u, block.x - 64 * w));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < block.x; ++t)
+          th.emplace_back([=] {
+            threadIdx = dim3(t);
+            blockIdx = dim3(b, by, bz);
+            blockDim = block;
+            emu_tid = (int)t;
+            kernel(args...);
+          });
+        for (auto& x : th) x.join();
+        pthread_barrier_destroy(&emu_block_bar);
+        for (unsigned w = 0; w < (block.x + 63) / 64; ++w) pthread_barrier_destroy(&emu_waves[w].bar);
+      }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
 
