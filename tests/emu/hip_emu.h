@@ -48,6 +48,15 @@ static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 static pthread_barrier_t emu_block_bar;
 static inline void __syncthreads() { pthread_barrier_wait(&emu_block_bar); }
 static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+// explicitly rounded single operations (no contraction into an fma)
+static inline float __fmul_rn(float a, float b) {
+  volatile float r = a * b;
+  return r;
+}
+static inline float __fadd_rn(float a, float b) {
+  volatile float r = a + b;
+  return r;
+}
 
 // builtins of the product's helpers that the emulated kernels do not execute (common.h parses them)
 #define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, hi) (w)
