@@ -57,7 +57,8 @@ def build(kernel_file):
         common = re.sub(pat, rep, common)
         kern = re.sub(pat, rep, kern)
     # dynamic LDS: the whole 160 KiB (one workgroup is alive at a time)
-    kern = re.sub(r'extern __shared__ (\w+) (\w+)\[\];', r'static \1 \2[163840 / sizeof(\1)];', kern)
+    kern = re.sub(r'extern __shared__ (?:__attribute__\(\(aligned\(\d+\)\)\) )?(\w+) (\w+)\[\];',
+                  r'static __attribute__((aligned(16))) \1 \2[163840 / sizeof(\1)];', kern)
     for name_, text in (('common.h', common), (kernel_file, kern)):
         assert 'asm volatile' not in text, f'an inline-assembly idiom of {name_} has no host restatement'
     src = f'#include "{os.path.join(HERE, "hip_emu.h")}"\n' + common + '\n' + kern

@@ -48,6 +48,9 @@ static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 static pthread_barrier_t emu_block_bar;
 static inline void __syncthreads() { pthread_barrier_wait(&emu_block_bar); }
 static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 // explicitly rounded single operations (no contraction into an fma)
 static inline float __fmul_rn(float a, float b) {
   volatile float r = a * b;
@@ -62,6 +65,7 @@ static inline float __fadd_rn(float a, float b) {
 #define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, hi) (w)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_logf(x) log2f(x) /* v_log_f32 is a base-2 logarithm (the hardware's is an approximation) */
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
