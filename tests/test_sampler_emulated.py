@@ -122,3 +122,67 @@ def test_emulated_unmask_schedule_is_the_references_loop(lib):
         off += rand_inc + len(heads) * expo_inc
     assert np.array_equal(step_of_row.numpy(), want_step) and (want_step > 0).all()
     assert np.array_equal(head_mask.numpy().view(np.uint32), want_mask)
+
+
+def test_emulated_sampling_tail_is_the_exponential_race_of_the_reference():
+    """S-3 (models/sample_model.py:300-306): ln_f, the row's own head, softmax(logits / temp), Categorical.sample() =
+    argmax(p / Exp(1)).  t2h_sample_heads in its one-launch form and its two-launch form on explicit noise, and the
+    two-launch form drawing the noise itself (element (row, class) of the tensor torch would have drawn at the head's
+    generator offset) -- against fp64 on the same noise."""
+    from text2human_amd._lib import SampleHeadsArgs
+    so = ctypes.CDLL(build_emu.build('sampler.hip'))
+    so.t2h_sample_heads.restype = ctypes.c_int
+    so.t2h_sample_heads.argtypes = [ctypes.POINTER(SampleHeadsArgs), c_vp]
+    so.emu_last_error.restype = ctypes.c_char_p
+    n, C, n_class, n_heads, temp = 24, 512, 256, 4, 0.9
+    g = torch.Generator().manual_seed(12)
+    hidden = torch.randn(n, C, generator=g) * 1.5 + 0.2
+    gamma, beta = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
+    w = torch.randn(n_heads, n_class, C, generator=g) * 0.08
+    tex = torch.randint(0, n_heads, (n,), generator=g)
+    rows = torch.tensor([0, 3, 4, 9, 10, 11, 17, 20, 22, 23], dtype=torch.int32)
+    seed, grid, inc = 2021, 256 * 24, 4   # (n * n_class = 6144 elements: 24 blocks of 256 threads, one call each)
+    offs = [4 * 100 + h * inc for h in range(n_heads)]
+    expo = [torch.from_numpy(-np.log(curand_uniform(raw_words(seed, offs[h], grid, n * n_class)).astype(np.float64))
+                             .astype(np.float32)).view(n, n_class).contiguous() for h in range(n_heads)]
+
+    def run(two_launch, in_kernel_noise):
+        a = SampleHeadsArgs()
+        x_t = torch.full((n,), -5, dtype=torch.int64)
+        out = torch.full((n_heads, n), -1, dtype=torch.int64)
+        ws = torch.zeros(len(rows), n_class)
+        a.hidden, a.lnf_gamma, a.lnf_beta, a.w_heads = hidden.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr()
+        a.rows, a.tex, a.x_t, a.out_idx = rows.data_ptr(), tex.data_ptr(), x_t.data_ptr(), out.data_ptr()
+        a.temp, a.n_rows, a.n, a.C, a.n_class, a.n_heads = temp, len(rows), n, C, n_class, n_heads
+        if two_launch:
+            a.logits_ws = ws.data_ptr()
+        if in_kernel_noise:
+            a.philox_seed, a.philox_grid_threads = seed, grid
+            for h in range(n_heads):
+                a.philox_offset[h] = offs[h]
+        else:
+            for h in range(n_heads):
+                a.expo[h] = expo[h].data_ptr()
+        assert so.t2h_sample_heads(ctypes.byref(a), None) == 0, so.emu_last_error()
+        return x_t, out
+
+    y = torch.nn.functional.layer_norm(hidden.double(), (C,), gamma.double(), beta.double(), 1e-5)
+    results = [run(False, False), run(True, False), run(True, True)]
+    for x_t, out in results:
+        untouched = torch.ones(n, dtype=torch.bool)
+        untouched[rows.long()] = False
+        assert (x_t[untouched] == -5).all() and (out[:, untouched] == -1).all()
+    for r in rows.tolist():
+        h = int(tex[r])
+        logits = (w[h].double() @ y[r]) / temp
+        score = torch.exp(logits - logits.max()) / expo[h][r].double()
+        top2 = score.topk(2)
+        clear = (top2.values[0] - top2.values[1]) > 1e-4 * top2.values[0]
+        for k, (x_t, out) in enumerate(results):
+            got = int(out[h, r])
+            assert x_t[r] == got + n_class * h and (out[:, r] >= 0).sum() == 1
+            if clear:   # (the third form's noise comes through the emulator's log2f: a few ulp from the table's)
+                assert got == int(top2.indices[0]), (r, k, got, top2)
+            else:
+                assert got in top2.indices.tolist()
+    assert torch.equal(results[0][1], results[1][1])   # one launch == two launches: the same fma chains
