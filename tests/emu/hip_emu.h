@@ -27,7 +27,11 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
-static thread_local dim3 threadIdx, blockIdx, blockDim;
+static thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+struct float2 {
+  float x, y;
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static thread_local int emu_tid;
 
 #define __global__
@@ -93,6 +97,12 @@ static inline T emu_shfl_xor(T v, int mask) {
   return r;
 }
 #define __shfl_xor(v, o, w) emu_shfl_xor(v, o)
+// wave vote: true on every lane if the predicate holds on any lane
+static inline int __any(int pred) {
+  int v = pred ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) v |= emu_shfl_xor(v, o);
+  return v;
+}
 // the DPP controls the product's wave reductions use (common.h: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror,
 // row_mirror, all lanes enabled) and v_readlane_b32, as lane exchanges
 static inline int emu_lane_from(int v, int src) {
@@ -138,6 +148,27 @@ static inline emu_f32x16 emu_mfma_f32_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_f16(a, b, c)
 
+// v_mfma_f32_32x32x2_f32 (gemm.hip, spatial_attn.hip): A lane l = row (l & 31), k = l >> 5; B lane l = column (l & 31),
+// the same k; D as above; two fused multiply-adds per element, k = 0 first
+static inline emu_f32x16 emu_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c) {
+  const int lane = emu_tid & 63;
+  emu_wave& W = emu_waves[emu_tid >> 6];
+  float* fa = reinterpret_cast<float*>(&W.a[0][0]);
+  float* fb = reinterpret_cast<float*>(&W.b[0][0]);
+  fa[lane] = a;
+  fb[lane] = b;
+  pthread_barrier_wait(&W.bar);
+  const int j = lane & 31, hh = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    c[r] = fmaf(fa[i], fb[j], c[r]);
+    c[r] = fmaf(fa[i + 32], fb[j + 32], c[r]);
+  }
+  pthread_barrier_wait(&W.bar);
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32(a, b, c)
+
 template <typename K, typename... A>
 static void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
   for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -152,6 +183,7 @@ static void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
             threadIdx = dim3(t);
             blockIdx = dim3(b, by, bz);
             blockDim = block;
+            gridDim = grid;
             emu_tid = (int)t;
             kernel(args...);
           });
