@@ -76,3 +76,21 @@ def build(kernel_file):
     subprocess.run([_host_clang(), '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-everything', cpp, '-o', lib],
                    check=True)
     return lib
+
+
+def load(kernel_file):
+    """-> ctypes handle of the emulation library of csrc/<kernel_file>, every product entry point it exports typed
+    from text2human_amd._lib.SIGNATURES (the table the product's own loader uses)"""
+    import ctypes
+    import sys
+    sys.path.insert(0, ROOT)
+    from text2human_amd import _lib
+    so = ctypes.CDLL(build(kernel_file))
+    for name, (res, args) in _lib.SIGNATURES.items():
+        try:
+            fn = getattr(so, name)
+        except AttributeError:
+            continue
+        fn.restype, fn.argtypes = res, args
+    so.emu_last_error.restype = ctypes.c_char_p
+    return so
