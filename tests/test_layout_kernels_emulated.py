@@ -129,7 +129,7 @@ def test_routed_head_argmax_and_folded_gather(vq):
 
 
 def test_q_sample_masked_ce_gather_and_round_cursor(sampler, misc):
-    B, T, num_t, mask_id = 3, 40, 256, 1024
+    B, T, num_t, mask_id = 3, 16, 256, 1024
     g = torch.Generator().manual_seed(6)
     x0 = torch.randint(0, 1024, (B, T), generator=g)
     u = torch.rand(B, T, generator=g)

@@ -79,7 +79,7 @@ def uniform_of(words):
     return np.where(u == np.float32(1.0), np.float32(0.0), u)   # uniform_(0, 1) reverses the bounds
 
 
-@pytest.mark.parametrize('seed,offset,grid', [(0, 0, 256), (2021, 4 * 77, 1024), (0x1234567890ABCDEF, 1 << 34, 256 * 40)])
+@pytest.mark.parametrize('seed,offset,grid', [(0, 0, 256), (2021, 4 * 77, 1024), (0x1234567890ABCDEF, 1 << 34, 256 * 8)])
 def test_emulated_uniform_and_exponential_draws(lib, seed, offset, grid):
     numel = 5 * grid + 123   # every thread makes two calls, the second one partly used
     out = torch.full((numel,), float('nan'))
@@ -134,14 +134,14 @@ def test_emulated_sampling_tail_is_the_exponential_race_of_the_reference():
     so.t2h_sample_heads.restype = ctypes.c_int
     so.t2h_sample_heads.argtypes = [ctypes.POINTER(SampleHeadsArgs), c_vp]
     so.emu_last_error.restype = ctypes.c_char_p
-    n, C, n_class, n_heads, temp = 24, 512, 256, 4, 0.9
+    n, C, n_class, n_heads, temp = 24, 512, 128, 4, 0.9
     g = torch.Generator().manual_seed(12)
     hidden = torch.randn(n, C, generator=g) * 1.5 + 0.2
     gamma, beta = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
     w = torch.randn(n_heads, n_class, C, generator=g) * 0.08
     tex = torch.randint(0, n_heads, (n,), generator=g)
-    rows = torch.tensor([0, 3, 4, 9, 10, 11, 17, 20, 22, 23], dtype=torch.int32)
-    seed, grid, inc = 2021, 256 * 24, 4   # (n * n_class = 6144 elements: 24 blocks of 256 threads, one call each)
+    rows = torch.tensor([0, 3, 9, 10, 17, 23], dtype=torch.int32)
+    seed, grid, inc = 2021, 256 * 12, 4   # (n * n_class = 3072 elements: 12 blocks of 256 threads, one call each)
     offs = [4 * 100 + h * inc for h in range(n_heads)]
     expo = [torch.from_numpy(-np.log(curand_uniform(raw_words(seed, offs[h], grid, n * n_class)).astype(np.float64))
                              .astype(np.float32)).view(n, n_class).contiguous() for h in range(n_heads)]

@@ -70,7 +70,7 @@ def test_emulated_codebook_argmin(vq, d):
 
 
 def test_emulated_texture_routed_argmin_and_gather(vq):
-    n, n_books, n_e, d = 24, 3, 128, 256
+    n, n_books, n_e, d = 12, 3, 64, 256
     z = rnd(n, d, seed=3)
     books = rnd(n_books, n_e, d, seed=4)
     tex = torch.randint(0, n_books, (n,), generator=torch.Generator().manual_seed(5))
