@@ -127,6 +127,7 @@ def test_kernel_choice_is_a_function_of_the_image_geometry_only(monkeypatch):
     assert ops.conv_halo_ok(1, 512, 256, 128, 128) and ops.conv_halo_ok(1, 64, 32, 512, 512)
     assert not ops.conv_halo_ok(8, 64, 32, 256, 256) and not ops.conv_halo_ok(8, 32, 16, 512, 512)
     assert not ops.conv_halo_ok(8, 24, 16, 32, 128) and not ops.conv_halo_ok(8, 512, 256, 128, 128, 'down')
+    assert ops.conv_halo_ok(8, 2048, 1024, 128, 128) and not ops.conv_halo_ok(8, 4096, 2048, 128, 128)   # 32-bit offsets per image
     monkeypatch.setenv('T2H_HALO_CONV', '0')
     assert not ops.conv_halo_ok(8, 512, 256, 128, 128)
     monkeypatch.setenv('T2H_HALO_CONV', '2')

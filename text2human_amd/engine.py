@@ -53,8 +53,8 @@ class VQGANStack:
         hw_out = h * w * (4 if mode == 'up' else 1)
         ws = self._ws(f'{conv}.w', hw_out, mode)
         pro = self._gn(x, norm, n_img, h * w) if norm is not None else None
-        if ws is not None and ops.conv_halo_ok(n_img, h * (2 if mode == 'up' else 1), w * (2 if mode == 'up' else 1),
-                                               cin, cout, mode):
+        if (ws is not None and x.stride(0) * h * w * 4 < 2**31
+                and ops.conv_halo_ok(n_img, h * (2 if mode == 'up' else 1), w * (2 if mode == 'up' else 1), cin, cout, mode)):
             # large levels: GroupNorm apply + swish + split happen while the 18 x 18-pixel halo of a 16 x 16 tile is
             # staged (csrc/conv_halo.hip) -- no elementwise pass, every input pixel read 1.27x instead of 9x
             return ops.conv_halo(x, ws, n_img, h, w, cin, cout, bias=P[f'{conv}.b'], residual=residual, mode=mode,

@@ -286,6 +286,9 @@ def conv_halo_ok(n_img, hout, wout, cin, cout, mode='same'):
     if knob == '0':
         return False
     served = mode in ('same', 'up') and hout % 16 == 0 and wout % 16 == 0 and cin % 32 == 0 and cout % 8 == 0 and cin <= 512
+    # (the kernel addresses an image and the weights with 32-bit byte offsets: beyond 2 GiB per image the two-kernel
+    # path serves the layer -- 4096 x 2048 pixels of 128 channels; the decoders' largest is 1024 x 512)
+    served = served and hout * wout * cin * 4 < 2**31 and cout * 9 * cin * 4 < 2**31
     return served and (knob == '2' or (hout // 16) * (wout // 16) * ((cout + 127) // 128) >= 32)
 
 
