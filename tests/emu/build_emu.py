@@ -34,7 +34,7 @@ def build(kernel_file):
     common = common.replace('#include <hip/hip_runtime.h>', '').replace('#pragma once', '')
     common = common.replace('#include "../../include/t2h_hip.h"', f'#include "{os.path.join(ROOT, "include", "t2h_hip.h")}"')
     common = common.replace('void t2h_set_error(const char* fmt, ...);', '')
-    kern = open(os.path.join(CSRC, kernel_file)).read().replace('#include "common.h"', '')
+    kern = open(os.path.join(CSRC, kernel_file)).read().replace('#include "common.h"', '').replace('#include <hip/hip_ext.h>', '')
     # the inline-assembly idioms of common.h and of the kernel files, restated for the host: a 16-byte global load /
     # write-through store becomes a copy (synchronous here), an LDS-DMA request a copy into the emulated LDS
     # (lane-linear, 16 bytes per lane), a counted wait and an opaque register copy become nothing
@@ -52,6 +52,13 @@ def build(kernel_file):
         (r'asm volatile\("s_waitcnt vmcnt\(%1\)" : "\+v"\(\w+\) : "n"\(N\)\);', ';'),
         (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ';'),
         (r'asm volatile\("" : "\+v"\(\w+\)\);', ';'),
+        # gemm_split.hip: LDS addresses are absolute there (lds0 = the address of `smem`): offsets from smem here
+        (r'\(unsigned\)\(uintptr_t\)smem', '0u'),
+        (r'asm volatile\("s_mov_b32 %0, m0[^;]*?global_load_lds_dwordx4[^;]*?: "=&s"\(keep\)\s*: "v"\(([\w\[\]]+)\), "s"\((\w+)\), "s"\((\w+)\)\s*: "memory"\);',
+         r'memcpy(smem + \3 + (emu_tid & 63) * 16, \2 + \1, 16);'),
+        (r'asm volatile\("s_waitcnt [a-z]+cnt\(0\)" ::: "memory"\);', ';'),
+        (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(\w+\) : "memory"\);', ';'),
+        (r'asm volatile\(""[^;]*?\);', ';'),   # empty templates (ablation stubs of never-defined switches, register pins)
     ]
     for pat, rep in rules:
         common = re.sub(pat, rep, common)

@@ -13,6 +13,7 @@
 // ones restated here.
 #pragma once
 #include <math.h>
+#include <cmath>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -66,7 +67,6 @@ static inline float __fadd_rn(float a, float b) {
 }
 
 // builtins of the product's helpers that the emulated kernels do not execute (common.h parses them)
-#define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, hi) (w)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_logf(x) log2f(x) /* v_log_f32 is a base-2 logarithm (the hardware's is an approximation) */
@@ -169,6 +169,116 @@ static inline emu_f32x16 emu_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c)
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32(a, b, c)
 
+// ---- OCP e4m3 (e4m3fn: bias 7, no infinities, 0x7f / 0xff = NaN, max 448) as gfx950's 8-bit conversions and matrix
+// instructions read it
+static inline float emu_e4m3_decode(uint8_t b) {
+  const int e = (b >> 3) & 15, m = b & 7;
+  float v;
+  if (e == 15 && m == 7) v = NAN;
+  else if (e == 0) v = ldexpf((float)m, -9);
+  else v = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+  return (b & 0x80) ? -v : v;
+}
+static inline uint8_t emu_e4m3_encode(float x) {  // round to nearest even; beyond +-448: the largest finite value
+  const uint8_t sgn = std::signbit(x) ? 0x80 : 0;
+  const float a = fabsf(x);
+  if (a != a) return sgn | 0x7f;
+  if (a < ldexpf(1.0f, -6)) {  // subnormal range: multiples of 2^-9
+    const int q = (int)nearbyintf(ldexpf(a, 9));
+    return sgn | (uint8_t)(q >= 8 ? 0x08 : q);
+  }
+  int e;
+  const float fr = frexpf(a, &e);  // a = fr 2^e, fr in [0.5, 1)
+  int ex = e - 1, q = (int)nearbyintf((fr * 2.0f - 1.0f) * 8.0f);
+  if (q == 8) {
+    q = 0;
+    ++ex;
+  }
+  if (ex > 8 || (ex == 8 && q == 7)) return sgn | 0x7e;
+  return sgn | (uint8_t)(((ex + 7) << 3) | q);
+}
+// v_cvt_pk_fp8_f32: two conversions into the low (hi = false) or high half of the old dword
+static inline unsigned emu_cvt_pk_fp8_f32(float a, float b, unsigned old, bool hi) {
+  const unsigned two = (unsigned)emu_e4m3_encode(a) | ((unsigned)emu_e4m3_encode(b) << 8);
+  return hi ? (old & 0x0000ffffu) | (two << 16) : (old & 0xffff0000u) | two;
+}
+#define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, hi) emu_cvt_pk_fp8_f32(a, b, w, hi)
+
+// v_mfma_f32_16x16x32_f16 (gemm_split.hip's few-rows kernel): A lane l = row (l & 15), k = 8 (l >> 4) .. + 7; B lane l =
+// column (l & 15), the same k; D register e of lane l = row 4 (l >> 4) + e, column (l & 15)
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+static inline emu_f32x4 emu_mfma_f32_16x16x32_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x4 c) {
+  const int lane = emu_tid & 63;
+  emu_wave& W = emu_waves[emu_tid >> 6];
+  for (int e = 0; e < 8; ++e) {
+    W.a[lane][e] = a[e];
+    W.b[lane][e] = b[e];
+  }
+  pthread_barrier_wait(&W.bar);
+  const int j = lane & 15, g = lane >> 4;
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * g + e;
+    float s = 0.f;
+    for (int k = 0; k < 32; ++k) s += (float)W.a[i + 16 * (k >> 3)][k & 7] * (float)W.b[j + 16 * (k >> 3)][k & 7];
+    c[e] += s;
+  }
+  pthread_barrier_wait(&W.bar);
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_f16(a, b, c)
+
+// v_mfma_scale_f32_32x32x64_f8f6f4 / _16x16x128_f8f6f4 with e4m3 x e4m3 operands and unit scales (the only form the
+// product uses): a lane supplies 32 bytes = its row's (column's) 32 consecutive k of the lane's k group -- group
+// l >> 5 of two (32x32x64), l >> 4 of four (16x16x128); accumulator layouts as the fp16 instructions of the same shape
+typedef int emu_i32x8 __attribute__((ext_vector_type(8)));
+struct emu_wave8 {
+  uint8_t a[64][32], b[64][32];
+};
+static emu_wave8 emu_waves8[16];
+static inline void emu_deposit8(emu_i32x8 a, emu_i32x8 b) {
+  const int lane = emu_tid & 63;
+  emu_wave8& W8 = emu_waves8[emu_tid >> 6];
+  memcpy(W8.a[lane], &a, 32);
+  memcpy(W8.b[lane], &b, 32);
+}
+static inline emu_f32x16 emu_mfma_scale_32x32x64(emu_i32x8 a, emu_i32x8 b, emu_f32x16 c) {
+  const int lane = emu_tid & 63;
+  emu_wave& W = emu_waves[emu_tid >> 6];
+  emu_wave8& W8 = emu_waves8[emu_tid >> 6];
+  emu_deposit8(a, b);
+  pthread_barrier_wait(&W.bar);
+  const int j = lane & 31, hh = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += emu_e4m3_decode(W8.a[i + 32 * (k >> 5)][k & 31]) * emu_e4m3_decode(W8.b[j + 32 * (k >> 5)][k & 31]);
+    c[r] += s;
+  }
+  pthread_barrier_wait(&W.bar);
+  return c;
+}
+static inline emu_f32x4 emu_mfma_scale_16x16x128(emu_i32x8 a, emu_i32x8 b, emu_f32x4 c) {
+  const int lane = emu_tid & 63;
+  emu_wave& W = emu_waves[emu_tid >> 6];
+  emu_wave8& W8 = emu_waves8[emu_tid >> 6];
+  emu_deposit8(a, b);
+  pthread_barrier_wait(&W.bar);
+  const int j = lane & 15, g = lane >> 4;
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * g + e;
+    float s = 0.f;
+    for (int k = 0; k < 128; ++k) s += emu_e4m3_decode(W8.a[i + 16 * (k >> 5)][k & 31]) * emu_e4m3_decode(W8.b[j + 16 * (k >> 5)][k & 31]);
+    c[e] += s;
+  }
+  pthread_barrier_wait(&W.bar);
+  return c;
+}
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, fa, fb, x, sa, y, sb) emu_mfma_scale_32x32x64(a, b, c)
+#define __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, fa, fb, x, sa, y, sb) emu_mfma_scale_16x16x128(a, b, c)
+#define __builtin_amdgcn_s_barrier() pthread_barrier_wait(&emu_block_bar)
+#define __builtin_amdgcn_s_memtime() 0ull
+#define __builtin_amdgcn_s_memrealtime() 0ull
+
 template <typename K, typename... A>
 static void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
   for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -193,6 +303,8 @@ static void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
       }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
+typedef void* hipEvent_t;
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ev0, ev1, flags, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
 
 static char emu_err[512];
 #include <stdarg.h>
