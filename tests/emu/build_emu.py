@@ -52,15 +52,24 @@ def build(kernel_file):
         (r'asm volatile\("s_waitcnt vmcnt\(%1\)" : "\+v"\(\w+\) : "n"\(N\)\);', ';'),
         (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ';'),
         (r'asm volatile\("" : "\+v"\(\w+\)\);', ';'),
-        # gemm_split.hip: LDS addresses are absolute there (lds0 = the address of `smem`): offsets from smem here
-        (r'\(unsigned\)\(uintptr_t\)smem', '0u'),
+        # gemm_split.hip / attention.hip: LDS addresses are absolute there (the address of the kernel's LDS array, LDS_NAME
+        # below): offsets from that array here
+        (r'\(unsigned\)\(uintptr_t\)LDS_NAME\b', '0u'),
         (r'asm volatile\("s_mov_b32 %0, m0[^;]*?global_load_lds_dwordx4[^;]*?: "=&s"\(keep\)\s*: "v"\(([\w\[\]]+)\), "s"\((\w+)\), "s"\((\w+)\)\s*: "memory"\);',
-         r'memcpy(smem + \3 + (emu_tid & 63) * 16, \2 + \1, 16);'),
+         r'memcpy(LDS_NAME + \3 + (emu_tid & 63) * 16, \2 + \1, 16);'),
+        # a wave waiting for its OWN LDS traffic is a point all of its lanes are at (the hardware runs them in lockstep;
+        # attention.hip signals other waves right behind it): a wave-level rendezvous here.  (Only where every lane of
+        # the wave reaches it, which holds for the two places that use this form.)
+        (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', 'emu_wave_sync();'),
         (r'asm volatile\("s_waitcnt [a-z]+cnt\(0\)" ::: "memory"\);', ';'),
+        (r'asm volatile\("" ::: "memory"\);', '__atomic_thread_fence(__ATOMIC_SEQ_CST);'),
         (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(\w+\) : "memory"\);', ';'),
         (r'asm volatile\(""[^;]*?\);', ';'),   # empty templates (ablation stubs of never-defined switches, register pins)
     ]
+    m = re.search(r'\(unsigned\)\(uintptr_t\)(smem\w*)', kern)
+    lds_name = m.group(1) if m else 'smem'
     for pat, rep in rules:
+        pat, rep = pat.replace('LDS_NAME', lds_name), rep.replace('LDS_NAME', lds_name)
         common = re.sub(pat, rep, common)
         kern = re.sub(pat, rep, kern)
     # dynamic LDS: the whole 160 KiB (one workgroup is alive at a time)

@@ -83,6 +83,9 @@ struct emu_wave {
 };
 static emu_wave emu_waves[16];
 
+// all lanes of the calling wave are here (what lockstep execution gives the hardware for free)
+static inline void emu_wave_sync() { pthread_barrier_wait(&emu_waves[emu_tid >> 6].bar); }
+
 // wave-collective lane exchange (every lane of the wave must call it)
 template <typename T>
 static inline T emu_shfl_xor(T v, int mask) {
@@ -276,6 +279,13 @@ static inline emu_f32x4 emu_mfma_scale_16x16x128(emu_i32x8 a, emu_i32x8 b, emu_f
 #define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, fa, fb, x, sa, y, sb) emu_mfma_scale_32x32x64(a, b, c)
 #define __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, fa, fb, x, sa, y, sb) emu_mfma_scale_16x16x128(a, b, c)
 #define __builtin_amdgcn_s_barrier() pthread_barrier_wait(&emu_block_bar)
+// (attention.hip's barrier among the waves of a key half: a monotonic LDS counter, polled)
+#include <sched.h>
+#define __HIP_MEMORY_SCOPE_WORKGROUP 0
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, __ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_sleep(n) sched_yield()
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_memrealtime() 0ull
 
