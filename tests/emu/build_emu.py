@@ -27,43 +27,48 @@ def available():
     return _host_clang() is not None
 
 
-def build(kernel_file):
-    """-> path of the emulation library of csrc/<kernel_file> (rebuilt when a source changes)"""
-    name = kernel_file.replace('.hip', '')
+def build(kernel_file, transform=None, tag=''):
+    """-> path of the emulation library of csrc/<kernel_file> (rebuilt when a source changes).  transform(text) -> text
+    edits the kernel file's text first (negative controls: a dropped barrier, a wait count one too permissive); tag
+    names that build."""
+    name = kernel_file.replace('.hip', '') + tag
     common = open(os.path.join(CSRC, 'common.h')).read()
     common = common.replace('#include <hip/hip_runtime.h>', '').replace('#pragma once', '')
     common = common.replace('#include "../../include/t2h_hip.h"', f'#include "{os.path.join(ROOT, "include", "t2h_hip.h")}"')
     common = common.replace('void t2h_set_error(const char* fmt, ...);', '')
     kern = open(os.path.join(CSRC, kernel_file)).read().replace('#include "common.h"', '').replace('#include <hip/hip_ext.h>', '')
+    if transform is not None:
+        kern = transform(kern)
     # the inline-assembly idioms of common.h and of the kernel files, restated for the host: a 16-byte global load /
     # write-through store becomes a copy (synchronous here), an LDS-DMA request a copy into the emulated LDS
     # (lane-linear, 16 bytes per lane), a counted wait and an opaque register copy become nothing
     rules = [
+        # explicit vector-memory requests and counted waits -> the emulator's in-order request queue (hip_emu.h: executed
+        # at once, or -- emu_set_deferred(1) -- only when a wait forces them: the latest the hardware may land them)
         (r'asm volatile\("global_load_dwordx4 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "s"\((\w+)\) : "memory"\);',
-         r'memcpy(&\1, \3 + \2, 16);'),
+         r'emu_vm_issue(&\1, \3 + \2, 16);'),
         (r'asm volatile\("global_load_dwordx4 %0, %1, off" : "=v"\((\w+)\) : "v"\((\w+)\) : "memory"\);',
-         r'memcpy(&\1, \2, 16);'),
+         r'emu_vm_issue(&\1, \2, 16);'),
         (r'asm volatile\("global_store_dwordx4 %0, %1, off sc1\\n\\ts_nop 1" ::"v"\((\w+)\), "v"\((\w+)\) : "memory"\);',
          r'memcpy(\1, &\2, 16);'),
         (r'asm volatile\("global_store_dwordx2 %0, %1, off sc1\\n\\ts_nop 0" ::"v"\((\w+)\), "v"\((\w+)\) : "memory"\);',
          r'memcpy(\1, &\2, 8);'),
         (r'asm volatile\("s_mov_b32 %0, m0[^;]*global_load_lds_dwordx4[^;]*: "=&s"\(keep\) : "v"\((\w+)\), "s"\((\w+)\), "s"\(dst\) : "memory"\);',
-         r'memcpy(lds_dst + (emu_tid & 63) * 16, \2 + \1, 16);'),
-        (r'asm volatile\("s_waitcnt vmcnt\(%1\)" : "\+v"\(\w+\) : "n"\(N\)\);', ';'),
-        (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ';'),
+         r'emu_vm_issue(lds_dst + (emu_tid & 63) * 16, \2 + \1, 16);'),
+        (r'asm volatile\("s_waitcnt vmcnt\(%1\)" : "\+v"\(\w+\) : "n"\((\w+)\)\);', r'emu_vm_wait(\1);'),
+        (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\((\w+)\) : "memory"\);', r'emu_vm_wait(\1);'),
+        (r'asm volatile\("s_waitcnt vmcnt\(0\)" ::: "memory"\);', 'emu_vm_wait(0);'),
         (r'asm volatile\("" : "\+v"\(\w+\)\);', ';'),
         # gemm_split.hip / attention.hip: LDS addresses are absolute there (the address of the kernel's LDS array, LDS_NAME
         # below): offsets from that array here
         (r'\(unsigned\)\(uintptr_t\)LDS_NAME\b', '0u'),
         (r'asm volatile\("s_mov_b32 %0, m0[^;]*?global_load_lds_dwordx4[^;]*?: "=&s"\(keep\)\s*: "v"\(([\w\[\]]+)\), "s"\((\w+)\), "s"\((\w+)\)\s*: "memory"\);',
-         r'memcpy(LDS_NAME + \3 + (emu_tid & 63) * 16, \2 + \1, 16);'),
+         r'emu_vm_issue(LDS_NAME + \3 + (emu_tid & 63) * 16, \2 + \1, 16);'),
         # a wave waiting for its OWN LDS traffic is a point all of its lanes are at (the hardware runs them in lockstep;
         # attention.hip signals other waves right behind it): a wave-level rendezvous here.  (Only where every lane of
         # the wave reaches it, which holds for the two places that use this form.)
         (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', 'emu_wave_sync();'),
-        (r'asm volatile\("s_waitcnt [a-z]+cnt\(0\)" ::: "memory"\);', ';'),
         (r'asm volatile\("" ::: "memory"\);', '__atomic_thread_fence(__ATOMIC_SEQ_CST);'),
-        (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(\w+\) : "memory"\);', ';'),
         (r'asm volatile\(""[^;]*?\);', ';'),   # empty templates (ablation stubs of never-defined switches, register pins)
     ]
     m = re.search(r'\(unsigned\)\(uintptr_t\)(smem\w*)', kern)

@@ -83,6 +83,37 @@ struct emu_wave {
 };
 static emu_wave emu_waves[16];
 
+// ---- the vector-memory request queue of a thread (= of its wave: every lane issues the same sequence).  The kernels'
+// explicit requests (inline-assembly global loads into registers, LDS-DMA) and counted waits (s_waitcnt vmcnt(N): at
+// most N requests still in flight, and they return in order) go through here.  Immediate mode executes a request when
+// it is issued -- the earliest it can land.  Deferred mode (emu_set_deferred(1)) executes it only when a wait forces it
+// (or the thread ends) -- the LATEST the hardware may land it: data that is consumed before the wait that covers it is
+// stale, a count that is one too permissive gives a wrong result instead of a lucky one.
+struct emu_vm_op {
+  void* dst;
+  const void* src;
+  int n;
+};
+static thread_local std::vector<emu_vm_op> emu_vm_q;
+static int emu_vm_deferred = 0;
+extern "C" int emu_set_deferred(int on) {
+  const int old = emu_vm_deferred;
+  emu_vm_deferred = on;
+  return old;
+}
+static inline void emu_vm_issue(void* dst, const void* src, int n) {
+  if (!emu_vm_deferred) memcpy(dst, src, n);
+  else emu_vm_q.push_back(emu_vm_op{dst, src, n});
+}
+static inline void emu_vm_wait(int allow) {
+  size_t done = 0;
+  while (emu_vm_q.size() - done > (size_t)allow) {
+    const emu_vm_op& op = emu_vm_q[done++];
+    memcpy(op.dst, op.src, op.n);
+  }
+  emu_vm_q.erase(emu_vm_q.begin(), emu_vm_q.begin() + done);
+}
+
 // all lanes of the calling wave are here (what lockstep execution gives the hardware for free)
 static inline void emu_wave_sync() { pthread_barrier_wait(&emu_waves[emu_tid >> 6].bar); }
 
@@ -306,6 +337,7 @@ static void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
             gridDim = grid;
             emu_tid = (int)t;
             kernel(args...);
+            emu_vm_wait(0);  // (a wave's requests complete before it ends)
           });
         for (auto& x : th) x.join();
         pthread_barrier_destroy(&emu_block_bar);

@@ -17,9 +17,12 @@ from text2human_amd import ops  # noqa: E402
 pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang++ for the emulation build')
 
 
-@pytest.fixture(scope='module')
-def lib():
-    return build_emu.load('attention.hip')
+@pytest.fixture(scope='module', params=[0, 1], ids=['requests-land-at-issue', 'requests-land-at-the-wait'])
+def lib(request):
+    so = build_emu.load('attention.hip')
+    so.emu_set_deferred(request.param)   # (K / Vt tiles by LDS-DMA: landing at issue, or only at the kernel's own waits)
+    yield so
+    so.emu_set_deferred(0)
 
 
 def rnd(*shape, seed=0, scale=1.0):

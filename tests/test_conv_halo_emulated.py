@@ -21,10 +21,14 @@ from text2human_amd._lib import GemmArgs  # noqa: E402
 pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang++ for the emulation build')
 
 
-@pytest.fixture(scope='module', params=[1, 0], ids=['two-fragment-sets', 'first-version'])
+# (kernel variant, landing of the explicit vector-memory requests: at issue / as late as the counted waits allow --
+# tests/emu/hip_emu.h, emu_set_deferred: the second is what checks the s_waitcnt vmcnt(N) counts)
+@pytest.fixture(scope='module', params=[(1, 0), (1, 1), (0, 0), (0, 1)],
+                ids=['lds-dma-kernel', 'lds-dma-kernel-late-landing', 'first-version', 'first-version-late-landing'])
 def lib(request):
     so = ctypes.CDLL(build_emu.build('conv_halo.hip'))
-    so.t2h_conv_halo_force_variant(request.param)
+    so.t2h_conv_halo_force_variant(request.param[0])
+    so.emu_set_deferred(request.param[1])
     so.t2h_conv_halo_f32.restype = ctypes.c_int
     so.t2h_conv_halo_f32.argtypes = [ctypes.POINTER(GemmArgs), ctypes.c_void_p, ctypes.c_void_p]
     so.emu_last_error.restype = ctypes.c_char_p
@@ -132,3 +136,22 @@ def test_kernel_choice_is_a_function_of_the_image_geometry_only(monkeypatch):
     assert not ops.conv_halo_ok(8, 512, 256, 128, 128)
     monkeypatch.setenv('T2H_HALO_CONV', '2')
     assert ops.conv_halo_ok(1, 32, 16, 512, 512)
+
+
+def test_late_landing_catches_a_wait_count_that_is_one_too_permissive():
+    """negative control of the late-landing mode: the LDS-DMA kernel with `s_waitcnt vmcnt(N + 1)` in front of its barrier
+    (the weight tile of the next tap may still be in flight when the other waves read it) must give a wrong result."""
+    def relax(text):
+        old = 'ch_wait_vm_all<(t >= 1 && t <= 6) ? 3 : 2>();'
+        assert old in text
+        return text.replace(old, 'ch_wait_vm_all<(t >= 1 && t <= 6) ? 4 : 3>();')
+    so = ctypes.CDLL(build_emu.build('conv_halo.hip', transform=relax, tag='_relaxed_wait'))
+    so.t2h_conv_halo_f32.restype = ctypes.c_int
+    so.t2h_conv_halo_f32.argtypes = [ctypes.POINTER(GemmArgs), ctypes.c_void_p, ctypes.c_void_p]
+    so.emu_last_error.restype = ctypes.c_char_p
+    so.emu_set_deferred(0)
+    out, ref, _, _, _ = run(so, 1, 64, 128, 16, 16, 'same', True)
+    assert ((out.double() - ref).abs() <= 2e-5 + 2e-5 * ref.abs()).all()   # landing at issue: the count is never tested
+    so.emu_set_deferred(1)
+    out, ref, _, _, _ = run(so, 1, 64, 128, 16, 16, 'same', True)
+    assert not ((out.double() - ref).abs() <= 2e-5 + 2e-5 * ref.abs()).all(), 'a too permissive wait went unnoticed'

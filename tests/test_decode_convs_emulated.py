@@ -37,10 +37,13 @@ def norm():
         't2h_groupnorm_finalize_f32': [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]})
 
 
-@pytest.fixture(scope='module')
-def conv_split():
-    return _load('conv_split.hip', {'t2h_conv_split_f32': [ctypes.POINTER(GemmArgs), c_vp],
-                                    't2h_conv_split_force_tile': [ctypes.c_int]})
+@pytest.fixture(scope='module', params=[0, 1], ids=['requests-land-at-issue', 'requests-land-at-the-wait'])
+def conv_split(request):
+    so = _load('conv_split.hip', {'t2h_conv_split_f32': [ctypes.POINTER(GemmArgs), c_vp],
+                                  't2h_conv_split_force_tile': [ctypes.c_int]})
+    so.emu_set_deferred(request.param)   # (its staged pieces are explicit requests with exact vmcnt waits)
+    yield so
+    so.emu_set_deferred(0)
 
 
 @pytest.fixture(scope='module')

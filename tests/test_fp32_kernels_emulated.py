@@ -29,9 +29,12 @@ def _load(kernel_file, sigs):
     return so
 
 
-@pytest.fixture(scope='module')
-def gemm():
-    return _load('gemm.hip', {'t2h_gemm_f32': [ctypes.POINTER(GemmArgs), c_vp], 't2h_gemm_force_config': [ctypes.c_int]})
+@pytest.fixture(scope='module', params=[0, 1], ids=['requests-land-at-issue', 'requests-land-at-the-wait'])
+def gemm(request):
+    so = _load('gemm.hip', {'t2h_gemm_f32': [ctypes.POINTER(GemmArgs), c_vp], 't2h_gemm_force_config': [ctypes.c_int]})
+    so.emu_set_deferred(request.param)   # (register pieces in flight across two K tiles, counted waits)
+    yield so
+    so.emu_set_deferred(0)
 
 
 def rnd(*shape, seed=0, scale=1.0):

@@ -20,9 +20,14 @@ from text2human_amd._lib import GemmSplitArgs  # noqa: E402
 pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang++ for the emulation build')
 
 
-@pytest.fixture(scope='module')
-def lib():
-    return build_emu.load('gemm_split.hip')
+# (landing of the kernels' explicit vector-memory requests -- register loads, LDS-DMA: at issue, or only when a counted
+# wait forces it; the second mode is what checks the s_waitcnt vmcnt(N) counts, tests/emu/hip_emu.h)
+@pytest.fixture(scope='module', params=[0, 1], ids=['requests-land-at-issue', 'requests-land-at-the-wait'])
+def lib(request):
+    so = build_emu.load('gemm_split.hip')
+    so.emu_set_deferred(request.param)
+    yield so
+    so.emu_set_deferred(0)
 
 
 def rnd(*shape, seed=0, scale=1.0):
