@@ -23,8 +23,8 @@ pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang
 
 # (kernel variant, landing of the explicit vector-memory requests: at issue / as late as the counted waits allow --
 # tests/emu/hip_emu.h, emu_set_deferred: the second is what checks the s_waitcnt vmcnt(N) counts)
-@pytest.fixture(scope='module', params=[(1, 0), (1, 1), (0, 0), (0, 1)],
-                ids=['lds-dma-kernel', 'lds-dma-kernel-late-landing', 'first-version', 'first-version-late-landing'])
+@pytest.fixture(scope='module', params=[(1, 0), (1, 1), (0, 1)],
+                ids=['lds-dma-kernel', 'lds-dma-kernel-late-landing', 'first-version-late-landing'])
 def lib(request):
     so = ctypes.CDLL(build_emu.build('conv_halo.hip'))
     so.t2h_conv_halo_force_variant(request.param[0])
@@ -88,7 +88,7 @@ def run(lib, n_img, cin, cout, h, w, mode, use_pro, x_scale=1.0, residual=True):
 @pytest.mark.parametrize('n_img,cin,cout,h,w,mode,use_pro,residual', [
     (1, 32, 128, 16, 16, 'same', False, True),   # one tile, one channel group: borders on all four sides
     (1, 32, 128, 16, 16, 'same', False, False),  # ... without a residual: the GroupNorm sums come from the staged values
-    (2, 64, 96, 32, 16, 'same', True, True),     # two groups (both halo buffers), tiles stacked in y, clamped column tile
+    (1, 64, 96, 32, 16, 'same', True, True),     # two groups (both halo buffers), tiles stacked in y, clamped column tile
     (1, 96, 128, 8, 16, 'up', True, True),       # three groups (odd), nearest-x2 staging, tiles side by side in x
 ])
 def test_emulated_conv_halo_vs_fp64(lib, n_img, cin, cout, h, w, mode, use_pro, residual):

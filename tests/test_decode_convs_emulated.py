@@ -140,7 +140,7 @@ def test_emulated_groupnorm_finalize_vs_numpy(norm):
 @pytest.mark.parametrize('tile', [128, 256])
 @pytest.mark.parametrize('mode', ['same', 'up'])
 def test_emulated_conv_split_vs_fp64_and_vs_the_halo_kernel(norm, conv_split, conv_halo, tile, mode):
-    n_img, cin, cout, h, w = 1, 64, 128, (16 if mode == 'same' else 8), 16
+    n_img, cin, cout, h, w = 1, 64, 128, (16 if mode == 'same' else 8), (16 if mode == 'same' else 8)
     P = problem(n_img, cin, cout, h, w, mode)
     ups = 1 if mode == 'up' else 0
     M = n_img * P['ho'] * P['wo']
