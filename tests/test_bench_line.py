@@ -64,3 +64,17 @@ def test_compact_line_without_optional_parts():
         full.pop(k)
     c = json.loads(bench.compact_line(full))
     assert c['value'] > 0 and 'roofline' not in c
+
+
+def test_committed_counter_summaries_belong_to_these_kernel_sources():
+    """roofline.traffic is quoted from profiles/*_pmc_summary*.json only when that summary was taken from this tree's
+    kernel sources (digest over csrc/ and include/t2h_hip.h).  An edit to a kernel file without a new counter pass
+    turns the field null in the driver's line: this test says so before the round ends."""
+    for cfg in ('parsing', 'pose', 'parsing_b32'):
+        sd = bench.profile_side_data('gemm_split_kernel<x8>', cfg)
+        assert sd['traffic'] is not None, sd.get('traffic_note')
+        assert bench.kernel_src_digest() in sd['traffic_source']
+        assert 20e6 < sd['traffic'] < 400e6 and 0.05 < sd['mfma_util_pmc'] < 1
+        assert 5 < sd['avg_launch_us_rocprof'] < 200
+    # a kernel the summaries do not describe gets no figures
+    assert bench.profile_side_data('some_other_kernel', 'parsing') == {'traffic': None}
