@@ -19,21 +19,27 @@ configurations for 1 warm-up + 5 steps each and reports them under "other_config
 per-GPU share (sample_from_parsing at 32 images per GPU; its global batch at N = 8 IS configs[3]),
 and at N = 1 configs[2] (pose, B = 32) and configs[4]'s per-GPU share (hires, B = 8).
 
-For N > 1 the driver launches this file with torch.distributed.run; images are independent so
-the batch is sharded across ranks with no data-path collective (weak scaling: the headline line
-keeps configs[1]'s 8 images per GPU at every N, "other_configs.parsing_b32" keeps 32 per GPU);
-weights are synthesised on rank 0 and broadcast over RCCL.
+N > 1: either the driver launches this file with torch.distributed.run (one rank per GPU; WORLD_SIZE must
+equal --gpus), or plain `python bench.py --gpus N` spawns its own N ranks under torch.distributed.run
+(spawn_ranks).  Images are independent, so the batch is sharded across ranks with no data-path collective
+(weak scaling: the headline line keeps configs[1]'s 8 images per GPU at every N,
+"other_configs.parsing_b32" keeps 32 per GPU); weights are synthesised on rank 0 and broadcast over RCCL.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  roofline     -- dominant kernel (the split-precision GEMM of the sampler Linears: three fp16
-                  partial products per fp32 multiply) measured live with HIP events on the
-                  launch stream: `frac` = EXECUTED fp16 matrix FLOP/s over the 2.5 PFLOP/s dense
-                  16-bit peak, `frac_useful` = the reference's fp32 FLOP count over the same peak;
+  roofline     -- dominant kernel (the split-precision GEMM of the sampler Linears: per fp32 multiply the fp16
+                  hi*hi product + both cross terms in one 8-bit instruction on x8 operands; three fp16
+                  products with T2H_X8=0) measured live with HIP events that receive the kernel's own
+                  start / end: `frac` = EXECUTED matrix FLOP/s over the dense peak of that instruction
+                  mix (3750 TFLOP/s; 2500 on fp16 planes), `frac_useful` = the reference's fp32 FLOP
+                  count over the fp16 peak; `worst_instantiation` = the tile configuration furthest
+                  below that peak among those carrying >= 5 % of the kernel time;
   stages       -- per-stage times (HIP events) with the decode stage's compute AND HBM fractions;
   stages       also carry the sampler's schedule: (sample, step) pairs possible / needed / evaluated;
   parity       -- the split-precision step (sampler AND decoder) against the exact-fp32 step on the
                   same batch / seed: tokens, bottom indices, image;
-  cpu_baseline -- the oracle (CPU port of the reference path) timed on this box's host cores.
+  cpu_baseline -- kind "reference": the UNMODIFIED reference SampleFromParsingModel (oracle/_ref byte code through
+                  oracle/ref_shim.py) on this box's host cores, all sampling steps once; kind "port"
+                  (oracle/torch_ref.py, a bounded sample) only where the byte code is absent.
 """
 import argparse
 import json
@@ -60,6 +66,29 @@ GFLOP_IMAGE = dict(sampler_step=99.858, tokenizer=40.49, refine=2.19, decode=562
 # projections (models/archs/transformer_arch.py:271); the HIP path runs the head of a token's own
 # texture for the changed tokens only, so the work it EXECUTES per evaluation is the 24 layers
 GFLOP_SAMPLER_LAYERS = 99.858 - 18 * 2 * 512 * 1024 * 512 / 1e9
+# one evaluation of the 24 layers, fp32-equivalent (2 * MAC): the four Linears / the two attention products
+GFLOP_SAMPLER_LINEARS = 24 * 2 * 512 * (512 * 1536 + 512 * 512 + 2 * 512 * 2048) / 1e9   # 77.31
+GFLOP_SAMPLER_ATTN = 24 * 2 * 2 * 8 * 512 * 512 * 64 / 1e9                                 # 12.88
+
+
+def sampler_matrix_time_frac(evaluations, seconds, x8, pmc=None):
+    """Fraction of the sampler stage's time its matrix instructions need at their DENSE rates (the honest
+    sampler-wide utilisation).  Per fp32 multiply-add the kernels issue three partial products;
+    in units of the time ONE fp16 product takes on v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s):
+      attention (always fp16 planes)            3 units  (hi*hi + two cross terms on the fp16 instruction)
+      Linears on fp16 planes (T2H_X8=0)         3 units
+      Linears on x8 operands (default)          2 units  (hi*hi: 1; BOTH cross terms in one 8-bit instruction at
+                                                          twice the rate: 2 * 1/2)
+    -> frac = (u_lin * 77.31 + 3 * 12.88) GFLOP * evaluations / seconds / 2.5 PFLOP/s.  `pmc` (the counter figure of
+    the committed profile, SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE launch-weighted over the split GEMMs) is carried
+    beside it for comparison."""
+    u_lin = 2.0 if x8 else 3.0
+    units = (u_lin * GFLOP_SAMPLER_LINEARS + 3.0 * GFLOP_SAMPLER_ATTN) * 1e9 * evaluations
+    return {'matrix_time_frac': units / seconds / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            'matrix_time_units': {'linears': u_lin, 'attention': 3.0},
+            'mfma_util_pmc_gemms': pmc}
+
+
 DECODE_BYTES_IMAGE = dict(parsing=1.870e9, hires=7.48e9)
 DECODE_WEIGHT_BYTES = 216.5e6
 WORKLOADS = {
@@ -322,7 +351,7 @@ def profile_side_data(kernel_label, config):
     if src_cfg != config:
         out['traffic_note'] = 'GEMM rows of the pose configuration (same sampler shapes, M = 16384)'
     tag = '' if src_cfg == 'parsing' else f'_{src_cfg}'
-    rounds = ('r05', 'r04')  # newest first: the first summary taken from THIS tree's kernel sources is quoted
+    rounds = ('r06', 'r05', 'r04')  # newest first: the first summary taken from THIS tree's kernel sources is quoted
     stale = None
     for rnd in rounds:
         path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_summary{tag}.json')
@@ -335,6 +364,7 @@ def profile_side_data(kernel_label, config):
         rows = [r for r in d['rows'] if r['kernel'].startswith('gemm_split')]
         n = sum(r['launches'] for r in rows)
         if n:
+            out['per_kernel'] = {r['kernel']: {'mfma_util': r['mfma_util'], 'traffic_mb': r['traffic_mb']} for r in rows}
             out.update(traffic=sum(r['traffic_mb'] * r['launches'] for r in rows) / n * 1e6,
                        traffic_unit='bytes/launch',
                        mfma_util_pmc=sum(r['mfma_util'] * r['launches'] for r in rows) / n,
@@ -354,6 +384,10 @@ def profile_side_data(kernel_label, config):
         n = sum(r['calls'] for r in rows)
         if n:
             out['avg_launch_us_rocprof'] = sum(r['avg_us'] * r['calls'] for r in rows) / n
+            if d.get('total_kernel_ms'):
+                for r in rows:  # (the two tables may list a kernel under several grids: shares add up)
+                    e = out.setdefault('per_kernel', {}).setdefault(r['kernel'], {})
+                    e['share'] = e.get('share', 0.0) + r['total_ms'] / d['total_kernel_ms']
             out['rocprof_source'] = f'profiles/{os.path.basename(path)}'
             break
     return out
@@ -389,6 +423,26 @@ def init_dist(backend, dev):
         os.dup2(saved_fd, 1)
         os.close(saved_fd)
     return dist
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N ...` without a launcher: re-executes the same command under torch.distributed.run,
+    one rank per GPU on this node (rendezvous on 127.0.0.1, a free port), stdout / stderr passed through -- rank 0
+    prints the ONE JSON line.  Returns nothing; exits with the launcher's status if it is not 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # (dmabuf IPC: what RCCL needs on this pool's hosts)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *argv]
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
 
 
 def pin_launch_thread(local_rank, local_world):
@@ -458,6 +512,36 @@ class StubModel:
 # --------------------------------------------------------------------------- one configuration
 
 
+# tile configuration (ops.SPLIT_CFG_NAMES) -> the leading template arguments <BM, BN, WARPS_M, WARPS_N, KS, PP> of its
+# gemm_split_kernel instantiation as rocprofv3 prints them (csrc/gemm_split.hip, t2h_gemm_split_f32's dispatch)
+SPLIT_CFG_TEMPLATE = {'128x64': '128, 64, 2, 2, 1, 0', '128x128': '128, 128, 4, 2, 1, 0', '64x64': '64, 64, 2, 2, 1, 0',
+                      '128x64, 8 waves': '128, 64, 4, 2, 1, 0', '128x256': '128, 256, 4, 2, 1, 0',
+                      '128x64, 2 K groups': '128, 64, 2, 2, 2, 0', '256x128, ping-pong LDS-DMA': '256, 128, 4, 2, 1, 2',
+                      '128x192, ping-pong LDS-DMA': '128, 192, 4, 2, 1, 2'}
+
+
+def worst_instantiation(inst, side, x8):
+    """The split-GEMM instantiation furthest below its roofline among those that carry time (>= 5 % of all kernel time
+    by the committed kernel trace; all of them when no trace of these sources is committed):
+    {name, frac (live, executed / peak of the instruction mix), mfma_util_pmc, share (of all kernel time)}."""
+    rows = []
+    for name, e in inst.items():
+        m = name[len('gemm_split_kernel<'):-1]
+        tmpl = SPLIT_CFG_TEMPLATE.get(m)
+        full = f'gemm_split_kernel<{tmpl}, {1 if x8 else 0}>' if tmpl else None
+        pm = (side.get('per_kernel') or {}).get(full, {})
+        rows.append({'name': full or name, 'tile': m, 'frac': e['frac'], 'avg_us': e['avg_us'],
+                     'mfma_util_pmc': pm.get('mfma_util'), 'share': pm.get('share')})
+    if not rows:
+        return None
+    # (no trace of these sources committed: weigh by the live samples -- every 37th launch -- of the split GEMMs alone)
+    tot = sum(e.get('n', 0) * e['avg_us'] for e in inst.values()) or 1.0
+    for r, e in zip(rows, inst.values()):
+        r['share_of_gemm_time_live'] = e.get('n', 0) * e['avg_us'] / tot
+    heavy = [r for r in rows if (r['share'] if r['share'] is not None else r['share_of_gemm_time_live']) >= 0.05] or rows
+    return min(heavy, key=lambda r: r['frac'])
+
+
 def gemm_roofline(prof, config):
     """`roofline` object of the dominant GEMM instantiation (largest sampled time) from the HIP-event
     samples of ops.gemm_profile_*."""
@@ -523,7 +607,10 @@ def gemm_roofline(prof, config):
                          frac_of_peak_at_measured_clock=e['frac'] * MAX_CLOCK_GHZ / g)
             inst[k] = e
         r['all_gemm_kernels'].update(inst)
-    r.update(profile_side_data(dom['kernel'], config))
+    side = profile_side_data(dom['kernel'], config)
+    r.update({k: v for k, v in side.items() if k != 'per_kernel'})
+    if split and dom.get('by_cfg'):
+        r['worst_instantiation'] = worst_instantiation(inst, side, x8)
     if r.get('avg_launch_us_rocprof'):
         r['frac_rocprof_kernel_time'] = r['frac'] * r['avg_launch_us'] / r['avg_launch_us_rocprof']
         r['rocprof_vs_live_kernel_time'] = r['avg_launch_us_rocprof'] / r['avg_launch_us']
@@ -537,6 +624,12 @@ class ConfigRun:
         self.config, self.model, self.batch = config, model, batch
         self.sample_steps, self.set_seed, self.stub = sample_steps, set_seed, stub
         self.upscale = config == 'hires'
+
+    @property
+    def x8(self):
+        """the sampler's Linears run on x8 operands (fp16 hi*hi + both cross terms in one 8-bit instruction)"""
+        net = getattr(self.model, 'sampler_fn', None)
+        return bool(getattr(net, 'x8', False) and getattr(net, 'split', False) and getattr(net, '_x8', None) is not None)
 
     def step(self, events=None):
         """events: list that receives (stage name, start event, end event)."""
@@ -637,7 +730,7 @@ class ConfigRun:
                     host_calls_per_step=calls[-1], rounds=stats.get('rounds'))
 
 
-def stage_view(stage_ms, b, sample_steps, upscale, stats):
+def stage_view(stage_ms, b, sample_steps, upscale, stats, x8=False):
     """Per-stage times (HIP events on the launch stream) with the algorithmic rates of SURVEY.md 8(d)."""
     st = {k: {'ms_per_step': v} for k, v in stage_ms.items()}
     if 'sampler' in st:
@@ -653,11 +746,16 @@ def stage_view(stage_ms, b, sample_steps, upscale, stats):
                 sample_steps_possible=stats['sample_steps_possible'], sample_steps_needed=stats['sample_steps_needed'],
                 sample_steps_evaluated=stats['sample_steps_launched'], rounds=stats['rounds'],
                 ms_per_round=stage_ms['sampler'] / max(1, stats['rounds']),
-                executed_frac_of_16bit_peak=3.0 * ex / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                executed_note='3 fp16 partial products per fp32 multiply over the 24 layers (90.19 GFLOP fp32-equivalent) '
-                              'of the evaluations launched; a (sample, step) pair that changes no token is not '
-                              'evaluated (its logits are never read), and of the 18 head projections only the rows '
-                              'that are sampled are computed')
+                **sampler_matrix_time_frac(stats['sample_steps_launched'], t, x8),
+                executed_products_frac_of_16bit_peak=3.0 * ex / t / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                executed_note='matrix_time_frac: the time the matrix instructions of the evaluations launched need at '
+                              'their dense rates over the stage time -- Linears 2 fp16-time units per multiply on x8 '
+                              'operands (3 on fp16 planes), attention 3 (bench.sampler_matrix_time_frac).  '
+                              'executed_products_frac_of_16bit_peak counts three PRODUCTS per multiply at the fp16 '
+                              'rate whatever instruction ran them (the figure quoted until round 5; with x8 it '
+                              'overstates the pipe time by 3 / 2 on the Linears).  A (sample, step) pair that changes '
+                              'no token is not evaluated, and of the 18 head projections only the sampled rows are '
+                              'computed (90.19 GFLOP fp32-equivalent per evaluation)')
     if 'refine_decode' in st:
         t = stage_ms['refine_decode'] * 1e-3
         fl = ((GFLOP_IMAGE['decode_hires'] if upscale else GFLOP_IMAGE['decode']) + GFLOP_IMAGE['refine']) * b * 1e9
@@ -693,7 +791,7 @@ def side_config(name, run, steps, warmup, batch_per_gpu, world, dworld, dev, pro
               if r.get('step_ms_median') else {}),
            'config': {'workload': f'{wl["desc"]}, batch={batch_per_gpu}/GPU, {run.sample_steps} sampling steps ({wl["ref"]})',
                       'global_batch': batch_per_gpu * world},
-           'stages': stage_view(r['stage_ms'], batch_per_gpu, run.sample_steps, run.upscale, r['stats'])}
+           'stages': stage_view(r['stage_ms'], batch_per_gpu, run.sample_steps, run.upscale, r['stats'], x8=run.x8)}
     if not run.stub and profile:
         e = run.eager_profile(1)
         if e['prof']:
@@ -744,6 +842,10 @@ def compact_line(out):
                          **_pick(rf, ('frac_useful', 'avg_launch_us', 'avg_launch_us_rocprof', 'mfma_util_pmc',
                                       'main_loop_shader_clock_ghz', 'frac_of_peak_at_measured_clock',
                                       'launches_sampled', 'flop_per_launch'))}
+        wi = rf.get('worst_instantiation')
+        if wi:
+            c['roofline']['worst_instantiation'] = {'name': str(wi.get('name', ''))[:60],
+                                                    **_pick(wi, ('frac', 'mfma_util_pmc', 'share'))}
     cb = out.get('cpu_baseline')
     if cb:
         c['cpu_baseline'] = {'value': _r(cb.get('value')), 'unit': cb.get('unit'), 'cores': cb.get('cores'),
@@ -752,7 +854,7 @@ def compact_line(out):
     if st:
         c['stages_ms'] = {k: _r(v['ms_per_step']) for k, v in st.items()}
         sm, rd = st.get('sampler', {}), st.get('refine_decode', {})
-        c['sampler'] = _pick(sm, ('rounds', 'ms_per_round', 'sample_steps_evaluated', 'executed_frac_of_16bit_peak'))
+        c['sampler'] = _pick(sm, ('rounds', 'ms_per_round', 'sample_steps_evaluated', 'matrix_time_frac', 'mfma_util_pmc_gemms'))
         c['decode'] = _pick(rd, ('ms_per_image', 'hbm_frac', 'compute_frac_of_16bit_mfma_peak'))
     if 'exact_fp32_path' in out:
         c['exact_fp32_path'] = _pick(out['exact_fp32_path'], ('value', 'ms_per_step'))
@@ -827,8 +929,17 @@ def main(argv=None):
                                              args.cpu_threads or (os.cpu_count() or 1), args.cpu_repeats)),
               flush=True)
         return
+    launched = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ  # under torch.distributed.run (or T2H_FORCE_DIST's env)
+    if not launched and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) of the same
+        # command -- the line printed is rank 0's, with n_gpus = rccl_world = N
+        return spawn_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if launched and world != args.gpus and os.environ.get('T2H_FORCE_DIST') != '1':
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; '
+                         f'launch with --nproc-per-node {args.gpus} (or run plain `python bench.py --gpus {args.gpus}`, '
+                         'which spawns its own ranks)')
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
     stub = args.stub_model
@@ -993,7 +1104,9 @@ def main(argv=None):
         out['host_launches_per_round'] = 1 if res['launch_mode'] == 'graph' else eager['host_calls_per_step'] / rounds
     # ---- stage view (HIP events on the launch stream), incl. decode's compute AND HBM fractions
     if res['stage_ms']:
-        out['stages'] = stage_view(res['stage_ms'], batch_per_gpu, args.sample_steps, run.upscale, res['stats'])
+        out['stages'] = stage_view(res['stage_ms'], batch_per_gpu, args.sample_steps, run.upscale, res['stats'], x8=run.x8)
+        if 'matrix_time_frac' in out['stages'].get('sampler', {}):
+            out['stages']['sampler']['mfma_util_pmc_gemms'] = (out.get('roofline') or {}).get('mfma_util_pmc')
     # whole-path arithmetic rate on the reference FLOP count
     per_image = (GFLOP_IMAGE['sampler_step'] * args.sample_steps + GFLOP_IMAGE['tokenizer'] + GFLOP_IMAGE['refine']
                  + (GFLOP_IMAGE['decode_hires'] if run.upscale else GFLOP_IMAGE['decode'])

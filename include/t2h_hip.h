@@ -339,6 +339,12 @@ typedef struct t2h_sample_heads_args {
                                       [n, n_class] exponential_ tensor whose elements rows[i] draws (a host that
                                       reorders the samples of a batch keeps every row's own noise); NULL = rows[i] */
 } t2h_sample_heads_args;
+/* max |x| as the bits of the fp32 maximum, atomicMax'ed into *out_bits (the caller zeroes it; uint order = float order
+ * for non-negative values, so the result does not depend on the order of the updates): of an fp32 matrix, and of the
+ * fp16 hi plane of split rows / x8 rows.  Load-time plumbing of the x8 format's per-tensor scales (weights' own maxima,
+ * activation maxima of the checkpoint-only calibration evaluation) -- not on the sampling path. */
+int t2h_absmax_f32(const float* x, int32_t ldx, int64_t rows, int32_t C, uint32_t* out_bits, void* stream);
+int t2h_split_rows_absmax(const uint16_t* rows_split, int64_t rows, int32_t C, uint32_t* out_bits, void* stream);
 /* dst[i] = src[rows[i]], rows of row_bytes (multiple of 16) bytes */
 int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, int32_t n_rows, int32_t row_bytes, void* stream);
 /* element-by-element reproduction of `torch.empty(numel).exponential_()` on the device generator

@@ -39,6 +39,8 @@ class StubModel:
 
 
 def stub_state_dicts(opt):
+    if os.environ.get('T2H_STUB_LOAD_FAILS') == '1':   # a missing / corrupt .pth on rank 0
+        raise FileNotFoundError('stub: pretrained_sampler.pth is not there')
     if READS:  # how many processes read the "checkpoints"
         with open(READS, 'a') as f:
             f.write(f"{os.environ.get('RANK', 0)}\n")

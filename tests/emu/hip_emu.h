@@ -54,6 +54,11 @@ static pthread_barrier_t emu_block_bar;
 static inline void __syncthreads() { pthread_barrier_wait(&emu_block_bar); }
 static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicMax(uint32_t* p, uint32_t v) {
+  uint32_t old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return old;
+}
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 // explicitly rounded single operations (no contraction into an fma)

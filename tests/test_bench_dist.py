@@ -59,6 +59,33 @@ def test_bench_two_ranks_gloo():
     assert one['rccl_world'] == 1 and len(one['per_rank_image_checksum']) == 1
 
 
+@pytest.mark.timeout(300)
+def test_plain_python_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher -- the form the driver uses at N = 1 -- must
+    produce a 2-rank line by itself (bench.spawn_ranks re-executes the command under torch.distributed.run)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE',
+                                                             'MASTER_ADDR', 'MASTER_PORT', 'T2H_FORCE_DIST')}
+    env.update(T2H_NO_PIN='0', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--stub-model',
+           '--batch', '3']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_world'] == 2 and out['config']['global_batch'] == 6
+    assert len(out['per_rank_ms_per_step']) == 2
+
+
+def test_a_launcher_whose_world_size_differs_from_gpus_is_refused():
+    env = dict(os.environ, T2H_NO_PIN='0', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+           '--stub-model', '--batch', '3']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and not r.stdout.strip()
+
+
 def test_broadcast_state_dicts_roundtrip_single_process():
     from text2human_amd import shard
     sds = {'a': {'w': torch.randn(3, 4), 'i': torch.arange(5)}}

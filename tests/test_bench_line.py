@@ -78,3 +78,59 @@ def test_committed_counter_summaries_belong_to_these_kernel_sources():
         assert 5 < sd['avg_launch_us_rocprof'] < 200
     # a kernel the summaries do not describe gets no figures
     assert bench.profile_side_data('some_other_kernel', 'parsing') == {'traffic': None}
+
+
+def test_sampler_utilisation_weights_the_cross_terms_by_their_instruction_rate():
+    """with x8 operands the Linears' two cross terms run in ONE 8-bit instruction at twice the fp16
+    rate, so a Linear multiply costs 2 fp16-time units, not 3; attention keeps 3.  Pinned on round 5's canned run
+    (profiles/r05_bench_driver_cmd_detail.json: 1776 evaluations in 655.5 ms, quoted then as 0.293)."""
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_driver_cmd_detail.json')))
+    sm = full['stages']['sampler']
+    t, ev = sm['ms_per_step'] * 1e-3, sm['sample_steps_evaluated']
+    off = bench.sampler_matrix_time_frac(ev, t, x8=False)
+    on = bench.sampler_matrix_time_frac(ev, t, x8=True, pmc=0.18)
+    assert abs(off['matrix_time_frac'] - sm['executed_frac_of_16bit_peak']) < 1e-3      # fp16 planes: the old figure
+    lin, att = bench.GFLOP_SAMPLER_LINEARS, bench.GFLOP_SAMPLER_ATTN
+    assert abs(lin - 77.31) < 0.01 and abs(att - 12.88) < 0.01 and abs(lin + att - bench.GFLOP_SAMPLER_LAYERS) < 1e-3
+    want = sm['executed_frac_of_16bit_peak'] * (2 * lin + 3 * att) / (3 * (lin + att))
+    assert abs(on['matrix_time_frac'] - want) < 1e-3 and 0.205 < on['matrix_time_frac'] < 0.22   # "0.21", not 0.29
+    assert on['matrix_time_units'] == {'linears': 2.0, 'attention': 3.0} and on['mfma_util_pmc_gemms'] == 0.18
+    # and the stage view carries it (x8 on / off), next to the old three-products figure under its own name
+    stats = dict(sample_steps_possible=2048, sample_steps_needed=1776, sample_steps_launched=ev, rounds=226)
+    for x8, f in ((True, on), (False, off)):
+        st = bench.stage_view({'sampler': sm['ms_per_step']}, 8, 256, False, stats, x8=x8)['sampler']
+        assert abs(st['matrix_time_frac'] - f['matrix_time_frac']) < 1e-9
+        assert abs(st['executed_products_frac_of_16bit_peak'] - sm['executed_frac_of_16bit_peak']) < 1e-3
+    c = json.loads(bench.compact_line({**full, 'stages': {'sampler': {**st, 'ms_per_step': 1.0}}}))
+    assert 'matrix_time_frac' in c['sampler'] and 'executed_frac_of_16bit_peak' not in c['sampler']
+
+
+def test_worst_instantiation_of_the_compact_line():
+    """roofline.worst_instantiation{name, frac, mfma_util_pmc, share}: the tile configuration furthest below its peak
+    among those carrying >= 5 % of the kernel time -- on round 5's canned run q|k|v's 128x192 ping-pong tile (live
+    frac 0.187, 18 % of the kernel time; proj / fc2's 128x64 K-split tile follows at 0.199 with 30 %)."""
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_driver_cmd_detail.json')))
+    inst = {k: v for k, v in full['roofline']['all_gemm_kernels'].items() if 'frac' in v}
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r05_pmc_summary.json')))
+    ks = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_parsing_kernel_stats.json')))
+    side = {'per_kernel': {}}
+    for r in pmc['rows']:
+        if r['kernel'].startswith('gemm_split'):
+            side['per_kernel'][r['kernel']] = {'mfma_util': r['mfma_util']}
+    for r in ks['rows']:
+        if r['kernel'].startswith('gemm_split'):
+            side['per_kernel'].setdefault(r['kernel'], {})['share'] = r['total_ms'] / ks['total_kernel_ms']
+    wi = bench.worst_instantiation(inst, side, x8=True)
+    assert wi['name'] == 'gemm_split_kernel<128, 192, 4, 2, 1, 2, 1>' and abs(wi['frac'] - 0.187) < 1e-3
+    assert abs(wi['mfma_util_pmc'] - 0.17) < 0.01 and abs(wi['share'] - 0.182) < 0.01
+    # an instantiation below 5 % of the kernel time is not the one reported, however low its frac
+    inst2 = dict(inst, **{'gemm_split_kernel<64x64>': {'frac': 0.01, 'avg_us': 5.0}})
+    side['per_kernel']['gemm_split_kernel<64, 64, 2, 2, 1, 0, 1>'] = {'share': 0.001, 'mfma_util': 0.01}
+    assert bench.worst_instantiation(inst2, side, x8=True)['name'] == wi['name']
+    # no committed profile of these sources: every instantiation counts, the side fields are null
+    wi0 = bench.worst_instantiation(inst, {}, x8=True)
+    assert wi0['name'] == wi['name'] and wi0['share'] is None and wi0['mfma_util_pmc'] is None
+    full['roofline']['worst_instantiation'] = wi
+    c = json.loads(bench.compact_line(full))
+    assert set(c['roofline']['worst_instantiation']) == {'name', 'frac', 'mfma_util_pmc', 'share'}
+    assert len(bench.compact_line(full)) < 6000

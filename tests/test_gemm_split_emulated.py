@@ -147,3 +147,26 @@ def test_emulated_split_row_producers_write_the_host_packers_bytes(lib):
     rc = norm.t2h_layernorm_x8_f32(x.data_ptr(), g.data_ptr(), b.data_ptr(), y8.data_ptr(), rows, C, 1e-5, scale, ovf.data_ptr(), None)
     assert rc == 0, norm.emu_last_error()
     assert torch.equal(y8.view(torch.uint8), x8_rows_cpu(y, scale).view(torch.uint8)) and int(ovf[0]) == 0
+
+
+def test_emulated_x8_producers_flag_the_fp16_range_under_a_small_scale():
+    """with a tensor scale <= 2^-8 a value in [65504, 448 / s) overflows the fp16 hi plane while the 8-bit
+    planes still hold it -- the 8-column store must raise bit 0 (fp16 range) on its own, not only behind the 8-bit
+    range test.  LayerNorm with a huge gamma produces such values; `x8_scale_for` itself never returns a scale that
+    small any more (448 / s stays below 65504)."""
+    norm = build_emu.load('norm.hip')
+    rows, C = 5, 512
+    x = rnd(rows, C, seed=11)
+    g, b = torch.full((C, ), 4.0e4), torch.zeros(C)   # outputs up to ~1.3e5
+    y8 = torch.zeros((rows, C // 32, 2, 32), dtype=torch.int16)
+    ovf = torch.zeros(1, dtype=torch.int32)
+    rc = norm.t2h_layernorm_x8_f32(x.data_ptr(), g.data_ptr(), b.data_ptr(), y8.data_ptr(), rows, C, 1e-5, 2.0 ** -9,
+                                   ovf.data_ptr(), None)
+    assert rc == 0, norm.emu_last_error()
+    assert int(ovf[0]) & 1, int(ovf[0])
+    # and values inside fp16's range but beyond the 8-bit planes' raise bit 1 only
+    ovf.zero_()
+    g = torch.full((C, ), 100.0)
+    rc = norm.t2h_layernorm_x8_f32(x.data_ptr(), g.data_ptr(), b.data_ptr(), y8.data_ptr(), rows, C, 1e-5, 4.0, ovf.data_ptr(), None)
+    assert rc == 0 and int(ovf[0]) == 2, int(ovf[0])
+    assert ops.x8_scale_for(1.0e5) == 2.0 ** -7 and 448.0 / ops.x8_scale_for(1.0e9) < 65504.0

@@ -221,7 +221,8 @@ def test_x8_range_overflow_falls_back_to_the_fp16_planes():
     seed_all(9)
     got = torch.stack(model.sample_fn(temp=1, sample_steps=10))     # x8: same tokens on this fixture
     assert torch.equal(got, want) and model.sampler_fn.x8 and model.sampler_fn.last_launch_mode == 'graph'
-    # scales 64x too large: every producer saturates -> bit 1 -> the call is re-run on the fp16 planes
+    # scales 64x too large: every producer saturates -> bit 1 -> THIS call is re-run on the fp16 planes
+    good = dict(model.sampler_fn._x8['a'])
     for k in model.sampler_fn._x8['a']:
         model.sampler_fn._x8['a'][k] *= 64.0
     model.sampler_fn._graphs = {}
@@ -229,5 +230,102 @@ def test_x8_range_overflow_falls_back_to_the_fp16_planes():
     seed_all(9)
     with pytest.warns(UserWarning, match='fp16-plane'):
         got = torch.stack(model.sample_fn(temp=1, sample_steps=10))
-    assert torch.equal(got, want) and not model.sampler_fn.x8
+    assert torch.equal(got, want)
     assert torch.equal(torch.cuda.get_rng_state(DEV), state)
+    # the fall-back is per call: the net is still an x8 net, and with its scales back the next call runs
+    # on x8 operands again (a call's result never depends on an earlier call)
+    assert model.sampler_fn.x8
+    model.sampler_fn._x8['a'].update(good)
+    model.sampler_fn._graphs = {}
+    seed_all(9)
+    got = torch.stack(model.sample_fn(temp=1, sample_steps=10))
+    assert torch.equal(got, want) and model.sampler_fn.x8 and model.sampler_fn.last_launch_mode == 'graph'
+
+
+def test_x8_result_is_a_pure_function_of_checkpoint_input_and_seed():
+    """the x8 scales come from the checkpoint alone (engine.SamplerNet.calibrate_x8: fixed
+    synthetic states at load), so a model object's history cannot change how a value is rounded.  Batch Y on a fresh
+    model, on a model that first sampled batch X (another batch size, another seed), and on a model that first met an
+    x8 range fall-back: bitwise-equal tokens, bitwise-equal uint8 images, the same generator state -- and the scales of
+    all models are equal."""
+    from parity_util import seed_all
+    from text2human_amd import defaults, options
+    from text2human_amd.models import SampleFromParsingModel, sample_model as SM
+    opt = options.dict_to_nonedict(defaults.sample_from_parsing())
+    sds = synthetic.make_state_dicts(opt, seed=1234)
+    X, Y = synthetic.parsing_batch(3, seed=41), synthetic.parsing_batch(2, seed=3)
+
+    def run_y(model):
+        model.feed_data(Y)
+        seed_all(2021)
+        top = model.sample_fn(temp=1, sample_steps=24)
+        _, u8 = model.decode_indices(top, want_u8=True)
+        assert model.sampler_fn.x8 and model.sampler_fn.last_launch_mode == 'graph'
+        return torch.stack(top).cpu(), u8.cpu(), torch.cuda.get_rng_state(DEV)
+
+    fresh = SampleFromParsingModel(opt, state_dicts=sds)
+    assert fresh.sampler_fn._x8 is not None   # calibrated at load, before any input
+    want = run_y(fresh)
+
+    seasoned = SampleFromParsingModel(opt, state_dicts=sds)
+    seasoned.feed_data(X)
+    seed_all(7)
+    seasoned.sample_fn(temp=1, sample_steps=9)
+    assert seasoned.sampler_fn._x8['a'] == fresh.sampler_fn._x8['a'] and seasoned.sampler_fn._x8['w'] == fresh.sampler_fn._x8['w']
+    got = run_y(seasoned)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+    # a model whose previous call fell back to the fp16 planes (scales sabotaged for that one call)
+    fell = SampleFromParsingModel(opt, state_dicts=sds)
+    good = dict(fell.sampler_fn._x8['a'])
+    for k in fell.sampler_fn._x8['a']:
+        fell.sampler_fn._x8['a'][k] *= 64.0
+    fell.feed_data(X)
+    seed_all(7)
+    SM._warned.discard('index sampler (x8 range)')
+    with pytest.warns(UserWarning, match='fp16-plane'):
+        fell.sample_fn(temp=1, sample_steps=5)
+    fell.sampler_fn._x8['a'].update(good)
+    fell.sampler_fn._graphs = {}
+    got = run_y(fell)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+    # the calibration states are a function of the checkpoint's shapes only
+    a, b = fresh.sampler_fn.x8_calibration_states(), seasoned.sampler_fn.x8_calibration_states()
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert int(a[0].max()) == 18432 and (a[0][0] == 18432).all() and (a[0][1] != 18432).all()
+
+
+def test_x8_result_does_not_depend_on_the_rank_that_computes_it():
+    """...nor on the process: inside a one-rank RCCL group (the sharded entry point's set-up: shard.broadcast_state_dicts,
+    a live communicator) the model has the plain model's scales and gives its tokens.  (A rank of a larger world
+    calibrates on the same checkpoint-only states -- there is no input it could differ by.)"""
+    import os
+    import torch.distributed as dist
+    from parity_util import seed_all
+    from text2human_amd import defaults, options, shard
+    from text2human_amd.models import SampleFromParsingModel
+    opt = options.dict_to_nonedict(defaults.sample_from_parsing())
+    sds = synthetic.make_state_dicts(opt, seed=1234)
+    Y = synthetic.parsing_batch(2, seed=3)
+    plain = SampleFromParsingModel(opt, state_dicts=sds)
+    plain.feed_data(Y)
+    seed_all(2021)
+    want = torch.stack(plain.sample_fn(temp=1, sample_steps=12)).cpu()
+    if dist.is_initialized():
+        pytest.skip('a process group is already up in this process')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        t = torch.ones(4, device=DEV)
+        dist.all_reduce(t)                      # (a live communicator beside the model's graphs)
+        sds_b = shard.broadcast_state_dicts(sds, dist.get_world_size(), torch.device('cuda', 0))
+        ranked = SampleFromParsingModel(opt, state_dicts=sds_b)
+        assert ranked.sampler_fn._x8['a'] == plain.sampler_fn._x8['a']
+        ranked.feed_data(Y)
+        seed_all(2021)
+        got = torch.stack(ranked.sample_fn(temp=1, sample_steps=12)).cpu()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(got, want)

@@ -172,3 +172,27 @@ def test_q_sample_masked_ce_gather_and_round_cursor(sampler, misc):
     for r in range(rounds):
         ok(sampler, sampler.t2h_schedule_advance(p(tbl), p(aux), None, p(ctr), p(cur), p(cur64), None, maxr, None))
         assert torch.equal(cur, tbl[r]) and torch.equal(cur64, aux[r]) and int(ctr[0]) == r + 1
+
+
+def test_absmax_of_a_matrix_and_of_a_split_row_hi_plane(misc):
+    """t2h_absmax_f32 / t2h_split_rows_absmax (load-time plumbing of the x8 scales: weights' and calibration
+    activations' maxima, read without a torch reduction): the bits of the fp32 maximum, atomicMax'ed into the caller's
+    word -- exact, order independent."""
+    from text2human_amd import ops
+    x = rnd(37, 96, seed=21, scale=3.0)
+    x[11, 5] = -17.25
+    bits = torch.zeros(2, dtype=torch.int32)
+    assert misc.t2h_absmax_f32(p(x), 96, 37, 96, p(bits), None) == 0, misc.emu_last_error()
+    assert bits.view(torch.float32)[0].item() == 17.25 and int(bits[1]) == 0
+    # a strided view (ldx > C), accumulated into a word that already holds a smaller / larger maximum
+    bits = torch.tensor([0, 0], dtype=torch.int32)
+    bits.view(torch.float32)[1] = 100.0
+    v = x[:, :64]
+    assert misc.t2h_absmax_f32(p(v), 96, 37, 64, p(bits), None) == 0
+    assert misc.t2h_absmax_f32(p(v), 96, 37, 64, p(bits[1:]), None) == 0
+    assert bits.view(torch.float32)[0].item() == 17.25 and bits.view(torch.float32)[1].item() == 100.0
+    hi, lo = ops.split_planes_host(x)
+    sp = torch.stack([hi.view(37, 3, 32), (lo * 0 + 999).half().view(37, 3, 32)], dim=2).contiguous().view(torch.int16)
+    bits = torch.zeros(1, dtype=torch.int32)
+    assert misc.t2h_split_rows_absmax(p(sp), 37, 96, p(bits), None) == 0, misc.emu_last_error()
+    assert bits.view(torch.float32)[0].item() == hi.float().abs().max().item()   # (the lo plane's 999 is not looked at)

@@ -31,8 +31,8 @@ def _config(tmp_path, name, n=5):
     return defaults.write_yaml(opt, str(tmp_path / f'{name}.yml')), names, opt
 
 
-def _launch(nproc, cfg, cwd, reads):
-    env = dict(os.environ, OMP_NUM_THREADS='1', T2H_STUB_READS_FILE=reads)
+def _launch(nproc, cfg, cwd, reads, **extra_env):
+    env = dict(os.environ, OMP_NUM_THREADS='1', T2H_STUB_READS_FILE=reads, **extra_env)
     if nproc == 1:
         cmd = [sys.executable, STUB, '-opt', cfg, '--batch-size', '2']
         for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
@@ -93,3 +93,18 @@ def test_two_ranks_write_the_union_once_each_on_their_own_slice(tmp_path):
     # an existing results directory is an error on EVERY rank (no rank hangs at a barrier)
     r3 = _launch(2, cfg, str(two_dir), str(tmp_path / 'reads3'))
     assert r3.returncode != 0 and 'FileExistsError' in r3.stderr
+
+
+@pytest.mark.timeout(300)
+def test_a_checkpoint_rank_0_cannot_load_ends_every_rank_with_the_error(tmp_path):
+    """rank 0 raising inside the checkpoint load used to leave the other ranks blocked in the broadcast
+    until the collective's timeout; the outcome now reaches every rank first and all of them raise."""
+    import time
+    cfg, _, _ = _config(tmp_path, 'badload')
+    d = tmp_path / 'run'
+    d.mkdir()
+    t0 = time.time()
+    r = _launch(2, cfg, str(d), str(tmp_path / 'reads'), T2H_STUB_LOAD_FAILS='1')
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert 'rank 0 could not load the checkpoints: FileNotFoundError' in r.stderr
+    assert r.stderr.count('rank 0 could not load the checkpoints') >= 2   # both ranks raised it

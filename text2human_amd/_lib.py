@@ -102,6 +102,8 @@ SIGNATURES = {
     't2h_mha_noncausal_f32': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     't2h_unmask_step': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
     't2h_sample_heads': (ctypes.c_int, [ctypes.POINTER(SampleHeadsArgs), c_vp]),
+    't2h_absmax_f32': (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    't2h_split_rows_absmax': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     't2h_gather_rows': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     't2h_philox_exponential_f32': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, c_vp, c_i64, c_vp]),
     't2h_philox_uniform_f32': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, c_vp, c_i64, c_vp]),

@@ -220,7 +220,10 @@ __device__ __forceinline__ void t2h_store_x8_8(uint16_t* base, int64_t row, int 
                                                int* ovf) {
   const float m = fmaxf(fmaxf(fmaxf(fabsf(va[0]), fabsf(va[1])), fmaxf(fabsf(va[2]), fabsf(va[3]))),
                         fmaxf(fmaxf(fabsf(vb[0]), fabsf(vb[1])), fmaxf(fabsf(vb[2]), fabsf(vb[3]))));
-  if (m * s >= T2H_E4M3_MAX) atomicOr(ovf, m >= 65504.0f ? 1 : 2);
+  // (the fp16 range is checked on its own: with a scale <= 2^-8 a value in [65504, 448 / s) would otherwise put inf
+  // into the hi plane without raising any bit)
+  if (m >= 65504.0f) atomicOr(ovf, 1);
+  else if (m * s >= T2H_E4M3_MAX) atomicOr(ovf, 2);
   t2h_f16x8 h;
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
   f32x2_ hs[4], ls[4];

@@ -331,6 +331,40 @@ extern "C" int t2h_tap_bias_map_f32(const float* tapc, float* out, int32_t B, in
   return T2H_OK;
 }
 
+// ---- max |x| of a tensor, as the BITS of the (non-negative) fp32 maximum: for non-negative floats the unsigned
+// integer order is the numeric order, so the result is one atomicMax per wave into a caller-zeroed word -- order
+// independent, hence deterministic.  Used once per checkpoint (engine.SamplerNet.calibrate_x8: the scales of the x8
+// format's 8-bit planes), never on the sampling path.  NaN / inf propagate as a huge bit pattern (the caller checks).
+__global__ void absmax_f32_kernel(const float* __restrict__ x, int ldx, int C, int64_t total, unsigned* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.f;
+  if (i < total) {
+    const int64_t r = i / C;
+    m = fabsf(x[r * ldx + (i - r * C)]);
+  }
+  unsigned b = __builtin_bit_cast(unsigned, m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)b, o, 64);
+    b = t > b ? t : b;
+  }
+  if ((threadIdx.x & 63) == 0 && b != 0) atomicMax(out, b);
+}
+
+// the same over the fp16 hi plane of split rows / x8 rows [rows][C/32][128 bytes]: the first 64 bytes of a tile
+__global__ void split_rows_absmax_kernel(const uint16_t* __restrict__ sp, int64_t total, unsigned* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // element of the hi planes: tile i / 32, k i % 32
+  float m = 0.f;
+  if (i < total) m = fabsf((float)reinterpret_cast<const _Float16*>(sp)[(i >> 5) * 64 + (i & 31)]);
+  unsigned b = __builtin_bit_cast(unsigned, m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)b, o, 64);
+    b = t > b ? t : b;
+  }
+  if ((threadIdx.x & 63) == 0 && b != 0) atomicMax(out, b);
+}
+
 // dst[i] = src[rows[i]] for rows of row_bytes (multiple of 16) bytes: compacts the changed token rows
 // (residual stream, attention output as split rows) for the last layer's row-wise tail
 __global__ void gather_rows_kernel(const char* __restrict__ src, const int32_t* __restrict__ rows,
@@ -354,5 +388,23 @@ extern "C" int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, 
                      static_cast<hipStream_t>(stream), static_cast<const char*>(src), rows, static_cast<char*>(dst),
                      row_bytes / 16, total);
   T2H_CHECK_LAUNCH("t2h_gather_rows");
+  return T2H_OK;
+}
+
+extern "C" int t2h_absmax_f32(const float* x, int32_t ldx, int64_t rows, int32_t C, uint32_t* out_bits, void* stream) {
+  T2H_REQUIRE(x && out_bits && rows > 0 && C > 0 && ldx >= C, "t2h_absmax_f32: bad arguments");
+  const int64_t total = rows * C;
+  hipLaunchKernelGGL(absmax_f32_kernel, grid1d(total), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, C, total,
+                     out_bits);
+  T2H_CHECK_LAUNCH("t2h_absmax_f32");
+  return T2H_OK;
+}
+
+extern "C" int t2h_split_rows_absmax(const uint16_t* rows_split, int64_t rows, int32_t C, uint32_t* out_bits, void* stream) {
+  T2H_REQUIRE(rows_split && out_bits && rows > 0 && C > 0 && C % 32 == 0, "t2h_split_rows_absmax: bad arguments");
+  const int64_t total = rows * C;
+  hipLaunchKernelGGL(split_rows_absmax_kernel, grid1d(total), dim3(256), 0, static_cast<hipStream_t>(stream), rows_split,
+                     total, out_bits);
+  T2H_CHECK_LAUNCH("t2h_split_rows_absmax");
   return T2H_OK;
 }

@@ -81,6 +81,9 @@ class BaseSampleModel():
         split_mha = os.environ.get('T2H_SPLIT_MHA', '1') != '0'
         self.sampler_fn = engine.SamplerNet(P, d_tf, self.opt['bert_n_head'], 'tf', split=split,
                                             split_mha=split_mha)
+        # x8 operands (engine.SamplerNet): weights packed and the per-tensor scales of the 8-bit planes fixed HERE,
+        # from the checkpoint alone -- nothing fed to the model later changes how a value is rounded
+        self.sampler_fn.ensure_x8()
 
     # ------------------------------------------------------------ helpers
     def _texture_tokens(self, texture_mask):
@@ -115,24 +118,28 @@ class BaseSampleModel():
         gen = torch.cuda.default_generators[self.device.index]
         state = gen.get_state()
         net = self.sampler_fn
-        for _ in range(3):  # x8 planes -> fp16 planes -> exact fp32, each at most once
-            try:
-                out = engine.sample_tokens(net, self.segm_tokens.contiguous(), tex_tok, sample_steps, self.mask_id,
-                                           temp=temp, noise=self.noise)
-                break
-            except engine.X8RangeError as e:
-                # an activation beyond 14x its calibration maximum: the 8-bit planes saturated, the fp16 planes are
-                # fine -- this net continues on the fp16-plane kernels (about 15 % slower), from the same generator state
-                if not _overflow_fallback('index sampler (x8 range)', 'T2H_X8', e, 'fp16-plane'):
-                    raise
-                net.x8 = False
-                net._graphs = {}
-                gen.set_state(state)
-            except engine.SplitOverflowError as e:
-                if net is not self.sampler_fn or not _overflow_fallback('index sampler', 'T2H_SPLIT_GEMM', e):
-                    raise
-                gen.set_state(state)
-                net = self._exact_sampler()
+        x8_was = net.x8
+        try:
+            for _ in range(3):  # x8 planes -> fp16 planes -> exact fp32, each at most once
+                try:
+                    out = engine.sample_tokens(net, self.segm_tokens.contiguous(), tex_tok, sample_steps, self.mask_id,
+                                               temp=temp, noise=self.noise)
+                    break
+                except engine.X8RangeError as e:
+                    # an activation beyond 14x its calibration maximum: the 8-bit planes saturated, the fp16 planes are
+                    # fine -- THIS call is re-run on the fp16-plane kernels (about 15 % slower) from the same generator
+                    # state; the next call starts on x8 again (the result of a call never depends on an earlier one)
+                    if not _overflow_fallback('index sampler (x8 range)', 'T2H_X8', e, 'fp16-plane'):
+                        raise
+                    net.x8 = False
+                    gen.set_state(state)
+                except engine.SplitOverflowError as e:
+                    if net is not self.sampler_fn or not _overflow_fallback('index sampler', 'T2H_SPLIT_GEMM', e):
+                        raise
+                    gen.set_state(state)
+                    net = self._exact_sampler()
+        finally:
+            self.sampler_fn.x8 = x8_was
         b = self.batch_size
         return [out[i].view(b, -1) for i in range(out.shape[0])]
 

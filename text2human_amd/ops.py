@@ -485,7 +485,21 @@ def x8_scale_for(max_abs, target=X8_TARGET_MAX):
     m = float(max_abs)
     if not (m > 0.0) or not math.isfinite(m):
         return 1.0
-    return 2.0 ** (math.ceil(math.log2(target / m)) - 1)
+    # (never below 2^-7: 448 / s then stays under fp16's 65504, so a value the 8-bit planes can hold never overflows
+    # the fp16 hi plane first)
+    return max(2.0 ** (math.ceil(math.log2(target / m)) - 1), 2.0 ** -7)
+
+
+def absmax_f32(x, out_bits):
+    """atomicMax of the fp32 bits of max |x| into out_bits[0] (int32 / uint32 device word the caller zeroed)."""
+    _chk_f32(x)
+    rows, C = x.shape
+    check(_lib.load().t2h_absmax_f32(_p(x), _rows(x), rows, C, _p(out_bits), _stream()), 't2h_absmax_f32')
+
+
+def split_rows_absmax(rows_split, rows, C, out_bits):
+    """The same over the fp16 hi plane of split rows / x8 rows."""
+    check(_lib.load().t2h_split_rows_absmax(_p(rows_split), rows, C, _p(out_bits), _stream()), 't2h_split_rows_absmax')
 
 
 def split_rows_x8(x, scale, out=None):

@@ -117,8 +117,20 @@ def run(pose=False, argv=None):
         loader = torch.utils.data.DataLoader(dataset=dataset, batch_size=args.batch_size, shuffle=False)
         if dist is not None:
             dev = torch.device('cuda', local_rank) if torch.cuda.is_available() else torch.device('cpu')
+            # the `.pth` files are read by rank 0 alone; its outcome reaches every rank BEFORE the broadcast, so that a
+            # missing / corrupt checkpoint ends all ranks with the error instead of leaving the others blocked in a
+            # collective until the RCCL timeout
+            sds0, err = None, [None]
+            if rank == 0:
+                try:
+                    sds0 = load_state_dicts(opt)
+                except Exception as e:  # noqa: BLE001 -- whatever the loader raised, every rank must learn it
+                    err[0] = f'{type(e).__name__}: {e}'
+            dist.broadcast_object_list(err, src=0)
+            if err[0] is not None:
+                raise RuntimeError(f'rank 0 could not load the checkpoints: {err[0]}')
             # (the helper's `world` argument is its "is distributed" switch)
-            sds = shard.broadcast_state_dicts(load_state_dicts(opt) if rank == 0 else None, 2, dev)
+            sds = shard.broadcast_state_dicts(sds0, 2, dev)
             model = create_model(opt, state_dicts=sds)
         else:
             model = create_model(opt)
