@@ -176,6 +176,11 @@ typedef struct t2h_gemm_split_args {
    * the overflow word when |x| s >= 448 (t2h_split_rows_x8_f32, t2h_layernorm_x8_f32, t2h_mha_split_f32 y_fmt 1). */
   int32_t fmt, out_fmt;
   float lo_mul, out_scale;
+  /* split over K across workgroups (0 / 1 = off; 2 or 4; x8 operands on the ping-pong tile configurations 8 / 10 / 11
+   * only): slice s of K is computed by its own workgroups and written as a PARTIAL fp32 tile to C + s * M * ldc (C
+   * holds ksplit * M rows; bias and residual go with slice 0); the caller sums the slices in a fixed order.  Built
+   * for the proj / fc2 experiment of round 6 (profiles/r06_fc2_128x128_splitk.log); the dispatcher never picks it. */
+  int32_t ksplit;
 } t2h_gemm_split_args;
 
 int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream);
@@ -200,7 +205,7 @@ int t2h_gemm_split_time_next_launch(void* start_event, void* stop_event);
 int t2h_gemm_split_probe_next_launch(void* dev_int64_buf);
 /* id of the tile configuration the dispatcher picks for `args` (profiling labels; ids as t2h_gemm_split_force_config) */
 int t2h_gemm_split_tile_config(const t2h_gemm_split_args* args);
-int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..3, 5, 6, 8 / 10 (ping-pong LDS-DMA, 256x128 / 128x192), 9 (few-rows kernel), -1 auto;
+int t2h_gemm_split_force_config(int cfg); /* tuning / tests: tile configuration 0..3, 5, 6, 8 / 10 / 11 (ping-pong LDS-DMA, 256x128 / 128x192 / 128x128), 9 (few-rows kernel), -1 auto;
                                               thread-local: it affects launches of the calling thread only */
 /* fp32 [rows, C] (row stride ldx) -> split rows */
 int t2h_split_rows_f32(const float* x, int32_t ldx, uint16_t* out, int64_t rows, int32_t C, int32_t* overflow_flag,

@@ -170,3 +170,43 @@ def test_emulated_x8_producers_flag_the_fp16_range_under_a_small_scale():
     rc = norm.t2h_layernorm_x8_f32(x.data_ptr(), g.data_ptr(), b.data_ptr(), y8.data_ptr(), rows, C, 1e-5, 4.0, ovf.data_ptr(), None)
     assert rc == 0 and int(ovf[0]) == 2, int(ovf[0])
     assert ops.x8_scale_for(1.0e5) == 2.0 ** -7 and 448.0 / ops.x8_scale_for(1.0e9) < 65504.0
+
+
+@pytest.mark.parametrize('cfg,M,N,K,ks', [(11, 128, 128, 128, 2), (8, 256, 128, 256, 4), (11, 128, 256, 64, 1)])
+def test_emulated_split_k_partial_tiles(lib, cfg, M, N, K, ks):
+    """ksplit (round-6 experiment, include/t2h_hip.h): slice s of K goes to its own workgroups and lands as a partial
+    fp32 tile at C + s * M * ldc; bias + residual travel with slice 0; the slices sum to the one-pass result.  Also
+    the 128x128 ping-pong instantiation (configuration 11) without a split."""
+    a, w = rnd(M, K, seed=21) * 1.3, rnd(N, K, seed=22, scale=0.25)
+    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
+    sa, sb = ops.x8_scale_for(a.abs().max()), ops.x8_scale_for(w.abs().max(), 256.0)
+    A, B = x8_rows_cpu(a, sa), x8_rows_cpu(w, sb)
+    ah, a8, al8 = ops.unpack_x8_rows_host(A, M, K, sa)
+    bh, b8, bl8 = ops.unpack_x8_rows_host(B, N, K, sb)
+    out = torch.full((ks * M, N), float('nan'))
+    g = GemmSplitArgs()
+    g.fmt, g.lo_mul, g.ksplit = 1, 1.0 / (ops.SPLIT_LO_SCALE * sa * sb), ks
+    g.A, g.B, g.C, g.bias, g.residual = A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr(), res.data_ptr()
+    g.M, g.N, g.K, g.ldc, g.ldr = M, N, K, N, N
+    old = lib.t2h_gemm_split_force_config(cfg)
+    try:
+        rc = lib.t2h_gemm_split_f32(ctypes.byref(g), None)
+    finally:
+        lib.t2h_gemm_split_force_config(old)
+    assert rc == 0, lib.emu_last_error()
+    kk = K // ks
+    for s in range(ks):
+        sl = slice(s * kk, (s + 1) * kk)
+        part = ah[:, sl].double() @ bh[:, sl].double().t() + (a8[:, sl].double() @ bl8[:, sl].double().t()
+                                                              + al8[:, sl].double() @ b8[:, sl].double().t()) / ops.SPLIT_LO_SCALE
+        if s == 0:
+            part = part + bias.double() + res.double()
+        err = (out[s * M:(s + 1) * M].double() - part).abs()
+        assert (err <= 3e-5 + 3e-5 * part.abs()).all(), (cfg, s, err.max().item())
+    # a split needs the ping-pong loop, x8 operands and a plain fp32 output
+    g.ksplit = 2
+    old = lib.t2h_gemm_split_force_config(6)
+    try:
+        assert lib.t2h_gemm_split_f32(ctypes.byref(g), None) != 0 and b'ksplit' in lib.emu_last_error()
+    finally:
+        lib.t2h_gemm_split_force_config(old)

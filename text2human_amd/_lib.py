@@ -42,7 +42,7 @@ class GemmSplitArgs(ctypes.Structure):
         ('A', c_vp), ('B', c_vp), ('C', c_vp), ('C_split', c_vp), ('bias', c_vp), ('residual', c_vp),
         ('M', c_i32), ('N', c_i32), ('K', c_i32), ('ldc', c_i32), ('ldr', c_i32), ('epi_act', c_i32),
         ('Vt', c_vp), ('vt_col0', c_i32), ('vt_T', c_i32), ('vt_hd', c_i32), ('overflow_flag', c_vp),
-        ('fmt', c_i32), ('out_fmt', c_i32), ('lo_mul', c_f32), ('out_scale', c_f32),
+        ('fmt', c_i32), ('out_fmt', c_i32), ('lo_mul', c_f32), ('out_scale', c_f32), ('ksplit', c_i32),
     ]
 
 

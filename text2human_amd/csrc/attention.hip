@@ -245,6 +245,9 @@ __device__ __forceinline__ void split8(const f32x16& x, f16x8& hi, f16x8& lo) {
   }
 }
 
+#ifndef T2H_MHA_PACKED
+#define T2H_MHA_PACKED 0  // (round-6 A/B, tools/mha_packed_ab.py; see the softmax of mha_split_pipe_kernel)
+#endif
 #ifdef T2H_MHA_TIMING
 __device__ long long* g_mha_timing = nullptr;  // debug builds only (tools/mha_split_ablate.py)
 #define TM_NOW() clock64()
@@ -473,13 +476,33 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
     f32x16 sn[2], sn_lo[2];
     if constexpr (NEXT) s_tile(Ks0 + (buf ^ 1) * DKV_TILE, sn, sn_lo);
     float psum = 0.f;
+#if T2H_MHA_PACKED
+    // (round 6: the exponent arguments and the row sum on register PAIRS -- v_pk_fma_f32 / v_pk_add_f32: 16 + 16
+    // instructions per sub-tile where the compiler had left 32 v_fma_f32 + a serial chain of 32 v_add_f32)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ sc2 = {SC, SC}, nm2 = {-m_run, -m_run};
+    f32x2_ ps2 = {0.f, 0.f};
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+#if T2H_MHA_PACKED
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2_ a = {sc[ks][r], sc[ks][r + 1]};
+        a = __builtin_elementwise_fma(a, sc2, nm2);
+        a[0] = __builtin_amdgcn_exp2f(a[0]);
+        a[1] = __builtin_amdgcn_exp2f(a[1]);
+        sc[ks][r] = a[0];
+        sc[ks][r + 1] = a[1];
+        ps2 += a;
+      }
+#else
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         sc[ks][r] = __builtin_amdgcn_exp2f(fmaf(sc[ks][r], SC, -m_run));
         psum += sc[ks][r];
       }
+#endif
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f16x8 pf[2];
@@ -500,6 +523,9 @@ __global__ __launch_bounds__(512) void mha_split_pipe_kernel(const uint16_t* __r
         o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[0], o_acc[1], 0, 0, 0);
       }
     }
+#if T2H_MHA_PACKED
+    psum = ps2[0] + ps2[1];
+#endif
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
     if constexpr (NEXT) {

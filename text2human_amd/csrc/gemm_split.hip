@@ -209,9 +209,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
   const int wm0 = (wave / WARPS_N) * WM, wn0 = (wave % WARPS_N) * WN;
   // XCD-aware tile mapping (see gemm.hip)
   const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+  // ksplit > 1 (ping-pong loop only; experiment of round 6, tools/fc2_split_k_bench.py): workgroup b + s * tiles
+  // takes the s-th slice of K of tile b and writes its PARTIAL tile to C + s * M * ldc (bias / residual with slice 0)
+  // (the integer division runs on the vector ALU: readfirstlane brings the workgroup-uniform result back to a scalar
+  // register, which the LDS-DMA's base-address operand needs)
+  const int ksid = (PP == 2 && p.ksplit > 1) ? __builtin_amdgcn_readfirstlane((int)blockIdx.x / (nbx * nby)) : 0;
   int m0, n0;
   {
-    const int total = nbx * nby, b = blockIdx.x;
+    const int total = nbx * nby, b = (int)blockIdx.x - ksid * (nbx * nby);
     const int xcd = b & 7, slot = b >> 3, q = total >> 3, r = total & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     int mt = lin / nbx, nt = lin - mt * nbx;
@@ -227,9 +232,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
     m0 = mt * BM;
     n0 = nt * BN;
   }
-  const int nk = p.K / (32 * KS);  // K tiles per group (host guarantees K % (32 KS) == 0)
+  const int nk_row = p.K / (32 * KS);  // K tiles per group over a whole row (host guarantees K % (32 KS) == 0)
+  const int nk = (PP == 2 && p.ksplit > 1) ? nk_row >> (p.ksplit >> 1) : nk_row;  // ... of this workgroup's slice (ksplit 2 or 4: a shift, scalar)
   const int last = nk - 1;
-  const int64_t row_b = (int64_t)nk * (SP_TILE_B * KS);  // bytes per split row
+  const int64_t row_b = (int64_t)nk_row * (SP_TILE_B * KS);  // bytes per split row
+  // first byte of the slice inside a row (readfirstlane on the product: the form the compiler keeps in scalar registers)
+  const int64_t k_base = (int64_t)__builtin_amdgcn_readfirstlane(ksid * nk) * SP_TILE_B;
   constexpr int K_STEP_B = SP_TILE_B * KS;               // bytes between a group's K tiles
 
   f32x16 acc[2][TM][TN];  // [0] ah*bh, [1] the 2^-11 terms ah*bl + al*bh
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
       // (no request past the last K tile: round 3 clamped kt to the last tile and re-fetched it twice per
       // workgroup -- 2 of 16 tiles at K = 512 -- into buffers nobody reads)
       if (kt > last) return;
-      const int64_t k0 = (int64_t)kt * SP_TILE_B;
+      const int64_t k0 = (int64_t)kt * SP_TILE_B + k_base;
       const char* const baseA = reinterpret_cast<const char*>(p.A) + k0;
       const char* const baseB = reinterpret_cast<const char*>(p.B) + k0;
 #pragma unroll
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) {
       const int col = n0 + wn0 + tj * 32 + l31;
-      const float bv = (p.bias && col < p.N && kg == 0) ? p.bias[col] : 0.f;
+      const float bv = (p.bias && col < p.N && kg == 0 && ksid == 0) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         Og[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * O_LD + tj * 32 + l31] = fin(ti, tj, r, bv);
@@ -703,13 +711,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N * KS) void gemm_split_kernel
         vb[e] = fmaxf(vb[e], 0.f);
       }
     }
-    if (p.residual) {
+    if (p.residual && ksid == 0) {
       va += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
       vb += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col + 4);
     }
     if (p.C) {
-      *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = va;
-      *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col + 4) = vb;
+      float* const Cs = p.C + (int64_t)ksid * p.M * p.ldc;  // (ksplit: slice s's partial tile)
+      *reinterpret_cast<f32x4*>(Cs + (int64_t)row * p.ldc + col) = va;
+      *reinterpret_cast<f32x4*>(Cs + (int64_t)row * p.ldc + col + 4) = vb;
     }
     if (p.C_split) {
       if (p.out_fmt == 1) t2h_store_x8_8<1>(p.C_split, row, p.N, col, va, vb, p.out_scale, ovf);  // (lanes 2j, 2j + 1: one 16-column group)
@@ -852,7 +861,12 @@ int launch_split(const t2h_gemm_split_args& a, hipStream_t s) {
                 a.vt_col0, BN % 128 ? 32 : BN);
   T2H_REQUIRE((int64_t)(a.M > a.N ? a.M : a.N) * a.K * 4 < (int64_t(1) << 31),
               "t2h_gemm_split_f32: operands are addressed with 32-bit byte offsets (each must span < 2 GiB)");
-  dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  if (ks > 1)
+    T2H_REQUIRE(PP == 2 && a.K % (32 * ks) == 0 && a.C && !a.C_split && !a.Vt && a.epi_act == 0,
+                "t2h_gemm_split_f32: ksplit=%d needs a ping-pong tile configuration (8, 10, 11), K %% %d == 0, an fp32 output "
+                "of ksplit * M rows and no activation / split-row / Vt output", ks, 32 * ks);
+  dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * ks);
   int* ovf = a.overflow_flag;
   launch_maybe_timed(gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, KS, PP, FMT>, grid, dim3(64 * WARPS_M * WARPS_N * KS), s, a,
                      ovf, g_probe);
@@ -949,6 +963,10 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
                 "t2h_gemm_split_f32: bad Vt routing (col0=%d T=%d hd=%d M=%d N=%d)", a.vt_col0, a.vt_T, a.vt_hd,
                 a.M, a.N);
   T2H_REQUIRE((a.fmt == 0 || a.fmt == 1) && (a.out_fmt == 0 || a.out_fmt == 1), "t2h_gemm_split_f32: fmt / out_fmt must be 0 or 1");
+  T2H_REQUIRE(a.ksplit >= 0 && a.ksplit <= 4 && a.ksplit != 3, "t2h_gemm_split_f32: ksplit must be 0 / 1 (off), 2 or 4");
+  if (a.ksplit > 1)
+    T2H_REQUIRE(a.fmt == 1 && (pick_split_cfg(a) == 8 || pick_split_cfg(a) == 10 || pick_split_cfg(a) == 11),
+                "t2h_gemm_split_f32: ksplit needs x8 operands on a ping-pong tile configuration (force 8, 10 or 11)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   t2h_gemm_split_args ax = a;
   if (ax.lo_mul == 0.f) ax.lo_mul = T2H_SPLIT_LO_INV;
@@ -971,9 +989,10 @@ extern "C" int t2h_gemm_split_f32(const t2h_gemm_split_args* args, void* stream)
       case 6: return launch_split<128, 64, 2, 2, 2, 0, 1>(ax, s);
       case 8: return launch_split<256, 128, 4, 2, 1, 2, 1>(ax, s);
       case 10: return launch_split<128, 192, 4, 2, 1, 2, 1>(ax, s);
+      case 11: return launch_split<128, 128, 4, 2, 1, 2, 1>(ax, s);  // (round-6 split-K experiment; never picked automatically)
       case 0: return launch_split<128, 64, 2, 2, 1, 0, 1>(ax, s);
       default:
-        t2h_set_error("t2h_gemm_split_f32: tile configuration %d is not built for x8 operands (0, 2, 6, 8, 9, 10)", cfg);
+        t2h_set_error("t2h_gemm_split_f32: tile configuration %d is not built for x8 operands (0, 2, 6, 8, 9, 10, 11)", cfg);
         return T2H_ERR_INVALID;
     }
   }

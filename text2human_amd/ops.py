@@ -101,7 +101,7 @@ def gemm_profile_active():
 
 SPLIT_CFG_NAMES = {0: '128x64', 1: '128x128', 2: '64x64', 3: '128x64, 8 waves', 5: '128x256', 6: '128x64, 2 K groups',
                    8: '256x128, ping-pong LDS-DMA', 9: 'few rows (16x16 per workgroup, K over 8 waves)',
-                   10: '128x192, ping-pong LDS-DMA'}
+                   10: '128x192, ping-pong LDS-DMA', 11: '128x128, ping-pong LDS-DMA'}
 
 
 def _probe_clock(buf):
@@ -542,7 +542,7 @@ def mha_split_x8(qk_split, ld_cols, vt, B, T, n_head, out_x8, scale):
 
 
 def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, residual=None, act=ACT_NONE,
-               vt=None, vt_col0=0, vt_T=0, vt_hd=64, x8=None, out_x8_scale=None):
+               vt=None, vt_col0=0, vt_T=0, vt_hd=64, x8=None, out_x8_scale=None, ksplit=0):
     """C = act(A @ W^T + bias) + residual on the fp16 matrix cores at fp32-class
     accuracy; a_split / w_split are split rows.  Writes fp32 `out` and / or the
     split-row form `out_split` of the result.  With `vt` the output columns from
@@ -557,6 +557,7 @@ def gemm_split(a_split, w_split, M, N, K, out=None, out_split=None, bias=None, r
         g.lo_mul = 1.0 / (SPLIT_LO_SCALE * float(x8[0]) * float(x8[1]))
     if out_x8_scale is not None:
         g.out_fmt, g.out_scale = 1, float(out_x8_scale)
+    g.ksplit = int(ksplit)  # (> 1: `out` holds ksplit * M rows of partial tiles; experiment, t2h_hip.h)
     g.A, g.B = a_split.data_ptr(), w_split.data_ptr()
     g.C = out.data_ptr() if out is not None else None
     g.C_split = out_split.data_ptr() if out_split is not None else None

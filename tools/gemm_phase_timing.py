@@ -33,7 +33,10 @@ else:
                     *(["-DT2H_DMA_POLICY=\" " + os.environ['T2H_DMA_POLICY'].replace('-', '') + "\""] if os.environ.get('T2H_DMA_POLICY') else []),
                     os.path.join(csrc, 'api.hip'), os.path.join(csrc, 'gemm_split.hip'), '-o', so], check=True)
 lib = ctypes.CDLL(so)
-CFGS = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 else [6, 8]
+# a configuration "11/2" = tile configuration 11 with a 2-way split over K across workgroups (t2h_gemm_split_args.ksplit:
+# partial fp32 tiles; proj / fc2 shapes with x8 operands only)
+CFGS = [(int(c.split('/')[0]), int(c.split('/')[1]) if '/' in c else 0)
+        for c in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['6', '8'])]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 M = 512 * B
 g0 = torch.Generator().manual_seed(0)
@@ -46,7 +49,7 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
     z = 0.0 if os.environ.get('T2H_TIMING_ZERO') == '1' else 1.0  # zero operands: the DVFS-free reference point
     a = (torch.randn(M * k * 2, generator=g0) * 0.5 * z).half().view(torch.int16).cuda()
     w = (torch.randn(n * k * 2, generator=g0) * 0.05 * z).half().view(torch.int16).cuda()
-    out = torch.zeros(M, n, device='cuda')
+    out = torch.zeros(4 * M, n, device='cuda')  # (room for up to 4 partial tiles per output tile)
     osp = torch.empty(M * n * 2, dtype=torch.int16, device='cuda')
     bias = torch.randn(n, generator=g0).cuda()
     g = GemmSplitArgs()
@@ -64,7 +67,10 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
     ovf = torch.zeros(1, dtype=torch.int32, device='cuda')
     g.overflow_flag = ovf.data_ptr()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for cfg in CFGS:
+    for cfg, ks in CFGS:
+        if ks > 1 and not (res and g.fmt == 1):
+            continue
+        g.ksplit = ks
         lib.t2h_gemm_split_force_config(cfg)
         tb = torch.zeros(16 * 4096, dtype=torch.int64, device='cuda')
         setter = lib.t2h_gemm_split_probe_next_launch
@@ -89,7 +95,7 @@ for name, (n, k, gelu, res) in dict(fc1=(2048, 512, True, False), qkv_nov=(1536,
         nb = t.shape[0]
         first = t[:, 0].min().item()
         med = lambda v: statistics.median(v.tolist())
-        print(f'{name:8s} cfg{cfg:2d}: launch {t_evt:6.1f} us | {nb:4d} blocks | entry skew med {med(t[:, 0] - first):5.2f} '
+        print(f'{name:8s} cfg{cfg:2d}{"/" + str(ks) if ks > 1 else "  "}: launch {t_evt:6.1f} us | {nb:4d} blocks | entry skew med {med(t[:, 0] - first):5.2f} '
               f'max {(t[:, 0] - first).max().item():5.2f} | prologue {med(t[:, 1] - t[:, 0]):5.2f} | main loop '
               f'{med(t[:, 2] - t[:, 1]):5.2f} (max {(t[:, 2] - t[:, 1]).max().item():5.2f}) | epilogue issue '
               f'{med(t[:, 3] - t[:, 2]):5.2f} | first entry -> last epilogue stamp '
