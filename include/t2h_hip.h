@@ -83,9 +83,21 @@ typedef struct t2h_gemm_args {
    * index inside the image (rows per image / 128 chunks) -- the partial layout
    * t2h_groupnorm_finalize_f32 reduces, so the GroupNorm that follows needs no pass over the tensor */
   double* gn_part_out;
+  /* t2h_gemm_f32, conv mode only (round 6): a caller-owned workspace lets the launch split K across workgroups -- the
+   * deep levels of the index-prediction / parsing UNets (unet_arch.py:470-481,657-674: a handful of pixels per image,
+   * K = 9 * 512 .. 9 * 1024) are 8-32 tiles that each stream megabytes of weights.  Slice s writes its partial tile to
+   * splitk_ws[s][M][N]; a second kernel of the same call sums the slices in slice order (bit-reproducible) and applies
+   * alpha / bias / residual / activation.  ksplit 0: the library chooses from (K, N, Hout * Wout) only -- never from
+   * the number of images, so an image's values do not depend on its batch --, 1 = no split, > 1 forces that many
+   * slices (needs splitk_ws_floats >= ksplit * M * N; any a_mode, batch 1).  splitk_ws NULL: never split. */
+  float* splitk_ws;
+  int64_t splitk_ws_floats;
+  int32_t ksplit;
 } t2h_gemm_args;
 
 int t2h_gemm_f32(const t2h_gemm_args* args, void* stream);
+/* the number of K slices t2h_gemm_f32 would use for `args` (1 = no split): callers size the workspace with it */
+int t2h_gemm_ksplit(const t2h_gemm_args* args);
 /* id of the tile configuration the dispatcher picks for `args` (profiling
  * labels): 0 64x64, 1 128x32, 2 128x64, 3 128x128, 4 128x64/K64, 5 128x128/K64,
  * 6 128x64/8 waves, 7 128x64/K64/8 waves, 8 128x128/K64/8 waves */
@@ -119,6 +131,10 @@ int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
  * with tables, an image and the weights < 2 GiB each. */
 int t2h_conv_halo_f32(const t2h_gemm_args* args, int32_t* overflow_flag, void* stream);
 int t2h_conv_halo_force_variant(int v); /* tuning / tests (thread-local): 1 = LDS-DMA weight tiles, two fragment sets, staged conversion (default); 0 = the first, register-staged kernel; returns the old value */
+/* experiment of round 6 (thread-local, 0 = off, the default; 2..8): the CUs' first workgroups of a launch of >= 1024
+ * workgroups start `populations` fractions of a tile apart, so that the HBM bursts of the prologues / epilogues of one
+ * population meet the main loops of the others; the values computed do not change; returns the old value */
+int t2h_conv_halo_set_stagger(int populations);
 /* 3x3 'same' convolution with 1..4 output channels (the decoders' conv_out, vqgan_arch.py:997,1026-1033) on
  * the vector ALU, exact fp32: out[pixel][co] = bias[co] + sum over taps, channels of
  * act(x * scale[img] + shift[img]) * w[co][tap][c] (scale NULL = no prologue; act 1 = swish), zero padding of

@@ -173,7 +173,7 @@ def top_codebook_entry(indices_list, texture_mask, books_sd, shape_hw=(32, 16)):
     indices_list: 18 x i64 [B, T]; returns f32 [B, 256, h, w]."""
     tex = texture_tokens(texture_mask, shape_hw).view(-1)
     e_dim = books_sd['embedding_list.0.weight'].shape[1]
-    zq = torch.zeros(tex.numel(), e_dim)
+    zq = torch.zeros(tex.numel(), e_dim, device=tex.device)
     for cb in range(18):
         sel = tex == cb
         if sel.any():
@@ -190,7 +190,7 @@ def bot_codebook_entry(indices_list, texture_mask, books_sd, shape_hw=(32, 16),
     F.fold them (k=2, s=2) -> f32 [B, 256, 2h, 2w]."""
     tex = texture_tokens(texture_mask, shape_hw).view(-1)
     e_dim = books_sd['embedding_list.0.weight'].shape[1]
-    zq = torch.zeros(tex.numel(), e_dim)
+    zq = torch.zeros(tex.numel(), e_dim, device=tex.device)
     for cb in range(18):
         sel = tex == cb
         if sel.any():
@@ -216,7 +216,7 @@ def texture_vq_forward(z, texture_mask, books_sd):
     zq = torch.zeros_like(zf)
     idx_lists = []
     for cb in range(18):
-        idx = torch.full((tex.numel(), ), -1, dtype=torch.long)
+        idx = torch.full((tex.numel(), ), -1, dtype=torch.long, device=tex.device)
         sel = tex == cb
         if sel.any():
             book = books_sd[f'embedding_list.{cb}.weight']
@@ -240,7 +240,7 @@ def spatial_texture_vq_forward(z, texture_mask, books_sd, spatial=2):
     zq = torch.zeros_like(pf)
     idx_lists = []
     for cb in range(18):
-        idx = torch.full((tex.numel(), ), -1, dtype=torch.long)
+        idx = torch.full((tex.numel(), ), -1, dtype=torch.long, device=tex.device)
         sel = tex == cb
         if sel.any():
             book = books_sd[f'embedding_list.{cb}.weight']
@@ -541,7 +541,7 @@ def bot_index_prediction(feature_top, texture_mask, unet_sd, head_sd, in_index=4
     feature_top [B,256,32,16] -> 18 x i64 [B,32,16] (-1 off-texture)."""
     b = feature_top.shape[0]
     tex = texture_tokens(texture_mask, (32, 16)).view(-1)
-    out = [torch.full((b * 512, ), -1, dtype=torch.long) for _ in range(18)]
+    out = [torch.full((b * 512, ), -1, dtype=torch.long, device=tex.device) for _ in range(18)]
     logits = multihead_fcn(unet(feature_top, unet_sd)[in_index], head_sd)
     for cb in range(18):
         roi = tex == cb

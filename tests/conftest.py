@@ -4,6 +4,11 @@ import time
 
 import pytest
 
+# the oracle / the unmodified reference as eager PyTorch-ROCm (tests/parity_util.py ORACLE_DEV, tests/test_gpu_vs_reference.py):
+# MIOpen's exhaustive search on the first call of every new convolution shape costs 5-14 s per stage on a fresh box
+# (profiles/r06_oracle_device_check.log); its immediate mode picks a solver from the shape alone -- no timing, so the
+# choice is also the same on every box
+os.environ.setdefault('MIOPEN_FIND_MODE', 'FAST')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -17,7 +22,7 @@ def pytest_configure(config):
 # GPU files in the order they should meet the clock: the newest arithmetic and the checks against the UNMODIFIED
 # reference first (alphabetically they ran last, i.e. were the first a slow box would cut), the long
 # full-length parity cases of earlier rounds last.  Files not listed keep their alphabetical place in the middle.
-_GPU_FIRST = ('test_gpu_x8.py', 'test_gpu_vs_reference.py', 'test_gpu_conv_halo.py', 'test_gpu_path.py',
+_GPU_FIRST = ('test_gpu_x8.py', 'test_gpu_oracle_device.py', 'test_gpu_vs_reference.py', 'test_gpu_conv_halo.py', 'test_gpu_path.py',
               'test_gpu_kernels.py', 'test_gpu_split.py')
 _GPU_LAST = ('test_gpu_configs.py', 'test_gpu_bench_parity.py')
 

@@ -12,6 +12,43 @@ from text2human_amd import engine
 DEV = 'cuda'
 ACT_TOL = 2e-4  # activations, on O(1) values
 
+# Where the ORACLE's convolutional stages (tokenizer, refine + decode, pose front end, encode side) execute in the
+# -m gpu tests.  Round 6: 'cuda' -- the same oracle source (oracle/torch_ref.py) as eager
+# PyTorch-ROCm fp32 on the box's GPU: refine + decode of 8 images 0.07 s instead of 14 s on the host cores, 32 images /
+# the 1024 x 512 decoder in proportion (profiles/r06_oracle_device_check.log) -- the driver's GPU step was mostly the
+# oracle's CPU side.  The chain stays pinned: oracle on the CPU == the unmodified reference (tests/
+# test_oracle_vs_reference.py, CPU suite); oracle on cuda:0 == oracle on the CPU (tests/test_gpu_oracle_device.py:
+# integer outputs equal, images within 5e-5); HIP path vs oracle on cuda:0 (everything else).
+# T2H_TEST_ORACLE_DEVICE=cpu runs every comparison against the CPU execution again (slow; the arbiter if the two
+# executions of the oracle ever disagree on a near-tie).
+import os
+ORACLE_DEV = os.environ.get('T2H_TEST_ORACLE_DEVICE', 'cuda')
+_SDS_ON_DEV = {}
+
+
+def odev(o, dev=None):
+    """tensors / dicts / lists of tensors -> the oracle's device"""
+    dev = dev or ORACLE_DEV
+    if torch.is_tensor(o):
+        return o.to(dev)
+    if isinstance(o, dict):
+        return {k: odev(v, dev) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(odev(v, dev) for v in o)
+    return o
+
+
+def osds(sds):
+    """the state dicts on the oracle's device (one copy per dict object, kept while the dict lives in the cache)"""
+    if ORACLE_DEV == 'cpu':
+        return sds
+    hit = _SDS_ON_DEV.get(id(sds))
+    if hit is None or hit[0] is not sds:
+        if len(_SDS_ON_DEV) >= 4:
+            _SDS_ON_DEV.clear()
+        hit = _SDS_ON_DEV[id(sds)] = (sds, odev(sds))
+    return hit[1]
+
 
 class RecordingNoise(R.TorchNoise):
     """TorchNoise that remembers the device generator state at the start of every step."""

@@ -111,6 +111,48 @@ def test_emulated_implicit_conv_with_the_groupnorm_prologue(gemm, mode):
     close(out, ref + res.double())
 
 
+def test_emulated_conv_split_over_k_for_the_deep_unet_levels(gemm):
+    """t2h_gemm_args.splitk_ws / ksplit (round 6; unet_arch.py:470-481: 4 x 2 pixels per image at 512 channels): K
+    slices on their own workgroups, partial tiles in the caller's workspace, summed in slice order with bias / ReLU /
+    residual behind.  The automatic slice count depends on (K, N, pixels per image) only: one image computed alone
+    and inside a batch gives the same bits."""
+    gemm.t2h_gemm_ksplit.restype = ctypes.c_int
+    gemm.t2h_gemm_ksplit.argtypes = [ctypes.POINTER(GemmArgs)]
+    n_img, cin, cout, h, w = 3, 64, 72, 4, 2
+    x = rnd(n_img, cin, h, w, seed=31)
+    wt, b = rnd(cout, cin, 3, 3, seed=32, scale=0.1), rnd(cout, seed=33)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), 1, 1)).permute(0, 2, 3, 1).reshape(-1, cout)
+    res = rnd(ref.shape[0], cout, seed=34)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous()
+    wp = weights.pack_conv3x3(wt)
+
+    def run(n, ksplit, ws_floats=None, rows_=rows):
+        M = n * h * w
+        out = torch.full((M, cout), float('nan'))
+        g = GemmArgs()
+        g.A, g.B, g.C, g.bias, g.residual = rows_.data_ptr(), wp.data_ptr(), out.data_ptr(), b.data_ptr(), res.data_ptr()
+        g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr = M, cout, 9 * cin, cin, 9 * cin, cout, cout
+        g.a_mode, g.epi_act, g.alpha, g.batch = 1, 2, 1.0, 1
+        g.Hin, g.Win, g.Cin, g.Hout, g.Wout, g.stride, g.pad, g.ups = h, w, cin, h, w, 1, 1, 0
+        ws = torch.full((ws_floats if ws_floats is not None else 16 * M * cout,), float('nan'))
+        g.splitk_ws, g.splitk_ws_floats, g.ksplit = ws.data_ptr(), ws.numel(), ksplit
+        ks = gemm.t2h_gemm_ksplit(ctypes.byref(g))
+        rc = gemm.t2h_gemm_f32(ctypes.byref(g), None)
+        return rc, ks, out
+
+    rc, ks_auto, out_auto = run(n_img, 0)
+    assert rc == 0 and ks_auto == 4, (rc, ks_auto, gemm.emu_last_error())  # K = 576: 18 K tiles, at least four per slice
+    close(out_auto, ref + res.double())
+    for ks in (1, 3, 9):   # no split; slices of unequal length (18 K tiles / 3 = 6, 18 / 9 = 2)
+        rc, got, out = run(n_img, ks)
+        assert rc == 0 and got == ks, gemm.emu_last_error()
+        close(out, ref + res.double())
+    rc, ks1, out1 = run(1, 0)   # image 0 alone: same slices, same bits
+    assert rc == 0 and ks1 == ks_auto and torch.equal(out1, out_auto[:h * w])
+    rc, _, _ = run(n_img, 0, ws_floats=ks_auto * n_img * h * w * cout - 1)
+    assert rc != 0 and b'workspace' in gemm.emu_last_error()
+
+
 def test_emulated_conv_out_on_the_vector_alu():
     so = _load('conv_small.hip', {'t2h_conv3x3_small_f32': [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32,
                                                             c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]})

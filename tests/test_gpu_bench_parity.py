@@ -40,7 +40,7 @@ from oracle import torch_ref as R
 from text2human_amd import defaults, engine, ops, options, synthetic
 from text2human_amd.models import SampleFromParsingModel
 
-from parity_util import ACT_TOL, DEV, account, forced_run, oracle_run, seed_all
+from parity_util import ACT_TOL, DEV, account, forced_run, odev, oracle_run, osds, seed_all
 
 pytestmark = pytest.mark.gpu
 B, STEPS, SEED = 8, 256, 2021          # bench.py defaults (BASELINE.json configs[1])
@@ -61,10 +61,11 @@ def _full_parity(batch_size, peaked, tag, all_paths=True):
     model = SampleFromParsingModel(opt, state_dicts=sds)  # default: split-precision sampler
     assert model.sampler_fn.split and model.sampler_fn.split_mha
     model.feed_data(batch)
-    with torch.no_grad():   # tokenizer on non-degenerate maps: exact against the CPU oracle at this batch size
-        tok_ref = R.segm_tokens(batch['segm'], sds['segm_encoder'], sds['segm_quant_conv'],
-                                sds['segm_quantizer']['embedding.weight']).view(batch_size, -1)
-    report['segm_token_mismatches'] = int((model.segm_tokens.cpu() != tok_ref).sum())
+    od = osds(sds)          # (the oracle's convolutional stages: parity_util.ORACLE_DEV)
+    with torch.no_grad():   # tokenizer on non-degenerate maps: exact against the oracle at this batch size
+        tok_ref = R.segm_tokens(odev(batch['segm']), od['segm_encoder'], od['segm_quant_conv'],
+                                od['segm_quantizer']['embedding.weight']).view(batch_size, -1)
+    report['segm_token_mismatches'] = int((model.segm_tokens.cpu() != tok_ref.cpu()).sum())
     ref, trace, rng_state = oracle_run(model.segm_tokens, batch['texture_mask'], sd_dev, STEPS, SEED)
     ref_t = torch.stack(ref)
     assert (ref_t >= 0).sum().item() == batch_size * 512  # every token sampled exactly once
@@ -101,15 +102,14 @@ def _full_parity(batch_size, peaked, tag, all_paths=True):
             split_vs_exact_mismatches=int((free['split_2xfp16'] != free['exact_fp32']).sum()),
             exact_vs_oracle_mismatches=int((free['exact_fp32'] != ref_t).sum()))
 
-    # refine + decode on the oracle's tokens (oracle on the CPU: exact direct fp32 convolutions):
-    # bottom indices exact, image within tolerance -- every image of the batch
+    # refine + decode on the oracle's tokens: bottom indices exact, image within tolerance -- every image of the batch
     with torch.no_grad():
-        ref_img, inter = R.refine_and_decode([t.cpu() for t in ref], batch['texture_mask'], sds)
+        ref_img, inter = R.refine_and_decode(odev(ref), odev(batch['texture_mask']), od)
     img, _, inters = model.decode_indices(ref, want_u8=True, return_inter=True)
     bot = torch.cat([d['bot_lists'].view(18, -1, 32, 16) for d in inters], 1).cpu()
-    ref_bot = torch.stack(inter['bot_idx']).view(18, batch_size, 32, 16)
+    ref_bot = torch.stack(inter['bot_idx']).view(18, batch_size, 32, 16).cpu()
     report['decode'] = dict(bot_index_mismatches=int((bot != ref_bot).sum()), bot_indices=int((ref_bot >= 0).sum()),
-                            img_max_abs_err=float((img.cpu() - ref_img).abs().max()), images=batch_size)
+                            img_max_abs_err=float((img.cpu() - ref_img.cpu()).abs().max()), images=batch_size)
 
     os.makedirs(OUT_DIR, exist_ok=True)
     with open(os.path.join(OUT_DIR, f'parity_{tag}.json'), 'w') as f:
@@ -338,8 +338,8 @@ def test_split_overflow_falls_back_to_exact_fp32_with_the_reference_tokens():
     with pytest.warns(UserWarning, match='exact-fp32'):
         img, _ = m2.decode_indices(top2)
     with torch.no_grad():
-        want, _ = R.refine_and_decode([t.cpu() for t in top2], batch['texture_mask'], sds2)
-    assert (img.cpu() - want).abs().max().item() < 2e-4
+        want, _ = R.refine_and_decode(odev(top2), odev(batch['texture_mask']), osds(sds2))
+    assert (img.cpu() - want.cpu()).abs().max().item() < 2e-4
     assert m2.decoder.use_split and m2.bot_decoder_res.use_split  # the next call starts on the split path again
 
 

@@ -10,6 +10,8 @@ from oracle import torch_ref as R
 from text2human_amd import defaults, options, synthetic
 from text2human_amd.models import SampleFromPoseModel
 
+from parity_util import odev, osds
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
@@ -36,10 +38,12 @@ def test_sample_from_pose_end_to_end(model, sds, opt):
     pb = synthetic.pose_batch(2, seed=8)
     model.feed_data(pb)
     model.generate_parsing_map()
+    od = osds(sds)   # (the oracle's convolutional stages run where parity_util.ORACLE_DEV says)
     with torch.no_grad():
-        segm_ref, logits = R.parsing_from_pose(pb['densepose'], pb['shape_attr'], sds['shape_embedder'],
-                                               sds['shape_encoder'], sds['shape_decoder'],
+        segm_ref, logits = R.parsing_from_pose(odev(pb['densepose']), odev(pb['shape_attr']), od['shape_embedder'],
+                                               od['shape_encoder'], od['shape_decoder'],
                                                opt['shape_attr_class_num'])
+    segm_ref, logits = segm_ref.cpu(), logits.cpu()
     bad = model.segm.cpu() != segm_ref
     t2 = logits.topk(2, dim=1).values
     margin = (t2[:, 0] - t2[:, 1]).unsqueeze(1)
@@ -49,8 +53,8 @@ def test_sample_from_pose_end_to_end(model, sds, opt):
     model.generate_quantized_segm()
     model.generate_texture_map()
     with torch.no_grad():
-        tok_ref = R.segm_tokens(segm_ref, sds['segm_encoder'], sds['segm_quant_conv'],
-                                sds['segm_quantizer']['embedding.weight']).view(2, -1)
+        tok_ref = R.segm_tokens(odev(segm_ref), od['segm_encoder'], od['segm_quant_conv'],
+                                od['segm_quantizer']['embedding.weight']).view(2, -1).cpu()
         mask_ref = R.texture_map(segm_ref, pb['upper_fused_attr'], pb['lower_fused_attr'],
                                  pb['outer_fused_attr'])
     assert torch.equal(model.segm_tokens.cpu(), tok_ref)
@@ -62,10 +66,10 @@ def test_sample_from_pose_end_to_end(model, sds, opt):
         model.noise = None
     with torch.no_grad():
         top_ref = R.sample_fn(tok_ref, mask_ref, sds['sampler'], 2, noise=R.SeededNoise(17, 'cpu'))
-        img_ref, _ = R.refine_and_decode(top_ref, mask_ref, sds)
+        img_ref, _ = R.refine_and_decode(odev(top_ref), odev(mask_ref), od)
     assert torch.equal(torch.stack(top).cpu(), torch.stack(top_ref))
     img, _ = model.decode_indices(top)
-    assert (img.cpu() - img_ref).abs().max().item() < 2e-4
+    assert (img.cpu() - img_ref.cpu()).abs().max().item() < 2e-4
 
 
 def test_upscaled_hierarchy_1024x512(model, sds):
@@ -77,18 +81,19 @@ def test_upscaled_hierarchy_1024x512(model, sds):
     model.texture_mask, model.batch_size = mask.to(DEV), 1
     img, _, inter = model.decode_indices([t.to(DEV) for t in top], return_inter=True, upscale=True)
     assert img.shape == (1, 3, 1024, 512)
+    od, top_o, mask_o = osds(sds), odev(top), odev(mask)
     with torch.no_grad():
-        pq, bq = sds['top_post_quant_conv'], sds['bot_post_quant_conv']
-        tq = F.conv2d(R.top_codebook_entry(top, mask, sds['top_quantize']), pq['weight'], pq['bias'])
-        bot_idx = R.bot_index_prediction(tq, mask, sds['guidance_encoder'], sds['index_decoder'])
-        qb = F.conv2d(R.bot_codebook_entry(bot_idx, mask, sds['bot_quantize']), bq['weight'], bq['bias'])
+        pq, bq = od['top_post_quant_conv'], od['bot_post_quant_conv']
+        tq = F.conv2d(R.top_codebook_entry(top_o, mask_o, od['top_quantize']), pq['weight'], pq['bias'])
+        bot_idx = R.bot_index_prediction(tq, mask_o, od['guidance_encoder'], od['index_decoder'])
+        qb = F.conv2d(R.bot_codebook_entry(bot_idx, mask_o, od['bot_quantize']), bq['weight'], bq['bias'])
         up = lambda t: F.interpolate(t, scale_factor=2.0, mode='nearest')
-        bh = R.decoder_res(up(qb), sds['bot_decoder_res'])
-        dec = R.decoder(up(tq), sds['decoder'], bot_h=bh)
+        bh = R.decoder_res(up(qb), od['bot_decoder_res'])
+        dec = R.decoder(up(tq), od['decoder'], bot_h=bh)
         ref = ((dec + 1) / 2).clamp(0, 1)
     got_bot = inter[0]['bot_lists'].view(18, 1, 32, 16).cpu()
-    assert torch.equal(got_bot, torch.stack(bot_idx))
-    assert (img.cpu() - ref).abs().max().item() < 2e-4
+    assert torch.equal(got_bot, torch.stack(bot_idx).cpu())
+    assert (img.cpu() - ref.cpu()).abs().max().item() < 2e-4
 
 
 # ---------------------------------------------------------------------------------------------
@@ -119,10 +124,12 @@ def test_sample_from_pose_batch_32_teacher_forced(model, sds, opt):
     model.feed_data(pb)
     model.generate_parsing_map()
     dv = lambda d: {k: v.to(DEV) for k, v in d.items()}
-    with torch.no_grad():   # (convolutional stages: the CPU oracle, exact direct fp32 convolutions)
-        segm_ref, logits = R.parsing_from_pose(pb['densepose'], pb['shape_attr'], sds['shape_embedder'],
-                                               sds['shape_encoder'], sds['shape_decoder'],
+    od = osds(sds)
+    with torch.no_grad():   # (convolutional stages of the oracle: parity_util.ORACLE_DEV)
+        segm_ref, logits = R.parsing_from_pose(odev(pb['densepose']), odev(pb['shape_attr']), od['shape_embedder'],
+                                               od['shape_encoder'], od['shape_decoder'],
                                                opt['shape_attr_class_num'])
+    segm_ref, logits = segm_ref.cpu(), logits.cpu()
     assert len(torch.unique(segm_ref)) >= 20, 'the fixture must give non-degenerate parsing maps'
     bad = model.segm.cpu() != segm_ref
     t2 = logits.topk(2, dim=1).values
@@ -138,12 +145,13 @@ def test_sample_from_pose_batch_32_teacher_forced(model, sds, opt):
     model.generate_texture_map()
     segm_cpu = model.segm.cpu()
     with torch.no_grad():
-        one_hot = F.one_hot(segm_cpu.squeeze(1).long(), 24).permute(0, 3, 1, 2).float()
-        qc = sds['segm_quant_conv']
-        z_ref = F.conv2d(R.encoder(one_hot, sds['segm_encoder']), qc['weight'], qc['bias'])
+        one_hot = F.one_hot(odev(segm_cpu).squeeze(1).long(), 24).permute(0, 3, 1, 2).float()
+        qc = od['segm_quant_conv']
+        z_ref = F.conv2d(R.encoder(one_hot, od['segm_encoder']), qc['weight'], qc['bias'])
         z_ref = z_ref.permute(0, 2, 3, 1).reshape(-1, z_ref.shape[1])
+        tok_ref = R.vq_l2_argmin(z_ref, od['segm_quantizer']['embedding.weight']).view(Bp, -1).cpu()
+        z_ref = z_ref.cpu()
         book = sds['segm_quantizer']['embedding.weight']
-        tok_ref = R.vq_l2_argmin(z_ref, book).view(Bp, -1)
         mask_ref = R.texture_map(segm_cpu, pb['upper_fused_attr'], pb['lower_fused_attr'], pb['outer_fused_attr'])
     x = ops.onehot_nhwc(model.segm.to(torch.float32).reshape(-1), 24, model.segm_cin_pad)
     z_hip, _, _ = model.segm_encoder.encode(x, Bp, 512, 256)
@@ -191,15 +199,16 @@ def test_upscaled_hierarchy_batch_of_8(model, sds):
     assert img.shape == (Bh, 3, 1024, 512) and u8.shape == (Bh, 1024, 512, 3)
     got_bot = torch.cat([d['bot_lists'].view(18, -1, 32, 16) for d in inter], 1).cpu()
     up = lambda t: F.interpolate(t, scale_factor=2.0, mode='nearest')
-    pq, bq = sds['top_post_quant_conv'], sds['bot_post_quant_conv']
+    od, top_o, mask_o = osds(sds), odev(top), odev(mask)
+    pq, bq = od['top_post_quant_conv'], od['bot_post_quant_conv']
     with torch.no_grad():
-        tq = F.conv2d(R.top_codebook_entry(top, mask, sds['top_quantize']), pq['weight'], pq['bias'])
-        bot_idx = R.bot_index_prediction(tq, mask, sds['guidance_encoder'], sds['index_decoder'])
-        assert torch.equal(got_bot, torch.stack(bot_idx))
-        qb = F.conv2d(R.bot_codebook_entry(bot_idx, mask, sds['bot_quantize']), bq['weight'], bq['bias'])
+        tq = F.conv2d(R.top_codebook_entry(top_o, mask_o, od['top_quantize']), pq['weight'], pq['bias'])
+        bot_idx = R.bot_index_prediction(tq, mask_o, od['guidance_encoder'], od['index_decoder'])
+        assert torch.equal(got_bot, torch.stack(bot_idx).cpu())
+        qb = F.conv2d(R.bot_codebook_entry(bot_idx, mask_o, od['bot_quantize']), bq['weight'], bq['bias'])
         for i in range(Bh):
-            bh = R.decoder_res(up(qb[i:i + 1]), sds['bot_decoder_res'])
-            dec = R.decoder(up(tq[i:i + 1]), sds['decoder'], bot_h=bh)
+            bh = R.decoder_res(up(qb[i:i + 1]), od['bot_decoder_res'])
+            dec = R.decoder(up(tq[i:i + 1]), od['decoder'], bot_h=bh)
             ref = ((dec + 1) / 2).clamp(0, 1)
-            err = (img[i:i + 1].cpu() - ref).abs().max().item()
+            err = (img[i:i + 1].cpu() - ref.cpu()).abs().max().item()
             assert err < 2e-4, (i, err)

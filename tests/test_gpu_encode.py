@@ -12,6 +12,8 @@ from oracle.make_golden import golden_inputs
 from text2human_amd import defaults, ops, options, synthetic
 from text2human_amd.models import create_model
 
+from parity_util import odev, osds  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
@@ -106,7 +108,7 @@ def _levels(model, image, mask, sds):
     from oracle import torch_ref as R
     b = image.shape[0]
     with torch.no_grad():
-        zt, zb = R.encode_latents(image, sds)
+        zt, zb = (t.cpu() for t in R.encode_latents(odev(image), osds(sds)))   # (parity_util.ORACLE_DEV)
     zt_ref = zt.permute(0, 2, 3, 1).reshape(-1, zt.shape[1])
     zb_ref = F.unfold(zb, (2, 2), stride=2).permute(0, 2, 1).reshape(-1, zb.shape[1] * 4)
     zt_hip = model._top_latent_rows.cpu()
@@ -133,7 +135,8 @@ def test_encode_golden_from_the_reference_modules(model_and_sds):
     g_top, g_bot = torch.from_numpy(g['top_indices']).long(), torch.from_numpy(g['bot_indices']).long()
     # the oracle's indices ARE the reference's on this input (pins the latents used for the accounting below)
     with torch.no_grad():
-        _, inter = R.reconstruct(gi['image'], gi['texture_mask'], sds)
+        _, inter = R.reconstruct(odev(gi['image']), odev(gi['texture_mask']), osds(sds))
+    inter = odev(inter, 'cpu')
     assert torch.equal(torch.stack(inter['top_indices']), g_top) and torch.equal(torch.stack(inter['bot_indices']), g_bot)
     (zt_h, zt_r, tb), (zb_h, zb_r, bb), tex = _levels(model, gi['image'], gi['texture_mask'], sds)
     n_t, lat_t = _account_level(zt_h, zt_r, tb, tex, top, g_top, 2e-4)
@@ -163,7 +166,8 @@ def test_reconstruct_matches_oracle_b2(model_and_sds):
     img = torch.rand(2, 3, 512, 256, generator=g) * 2 - 1
     mask = synthetic.parsing_batch(2, seed=77)['texture_mask']
     with torch.no_grad():
-        ref_rec, inter = R.reconstruct(img, mask, sds)
+        ref_rec, inter = R.reconstruct(odev(img), odev(mask), osds(sds))
+    ref_rec, inter = ref_rec.cpu(), odev(inter, 'cpu')
     model.feed_data(dict(image=img, texture_mask=mask))
     top = torch.stack([t.view(2, 32, 16) for t in model.top_indices_list]).cpu()
     bot = torch.stack(model.gt_indices_list).cpu()

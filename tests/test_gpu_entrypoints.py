@@ -14,6 +14,8 @@ from oracle import torch_ref as R
 from text2human_amd import data, defaults, options, sample_from_parsing, synthetic
 from text2human_amd.models import sample_model
 
+from parity_util import odev, osds
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 STEPS, BATCH, SEED = 6, 2, 2021
@@ -45,36 +47,38 @@ def _oracle_images(opt, sds, pose, recorded):
                                              pose_dir=opt['pose_dir'], ann_dir=opt['test_ann_file'])
     loader = torch.utils.data.DataLoader(dataset=ds, batch_size=BATCH, shuffle=False)
     sd_dev = {k: v.to(DEV) for k, v in sds['sampler'].items()}
+    od = osds(sds)   # (the oracle's convolutional stages: parity_util.ORACLE_DEV)
     out, checks = {}, []
     options.set_random_seed(SEED)
     with torch.no_grad():
         for i, batch in enumerate(loader):
             rec = recorded[i]
             if pose:
-                segm_ref, logits = R.parsing_from_pose(batch['densepose'], batch['shape_attr'], sds['shape_embedder'],
-                                                       sds['shape_encoder'], sds['shape_decoder'],
+                segm_ref, logits = R.parsing_from_pose(odev(batch['densepose']), odev(batch['shape_attr']), od['shape_embedder'],
+                                                       od['shape_encoder'], od['shape_decoder'],
                                                        opt['shape_attr_class_num'])
+                segm_ref, logits = segm_ref.cpu(), logits.cpu()
                 bad = rec['segm'].cpu() != segm_ref
                 t2 = logits.topk(2, dim=1).values
                 assert ((t2[:, 0] - t2[:, 1]).unsqueeze(1)[bad] < 1e-4).all() and bad.float().mean() < 1e-3
                 segm = rec['segm'].cpu()
                 mask = R.texture_map(segm, batch['upper_fused_attr'], batch['lower_fused_attr'], batch['outer_fused_attr'])
                 assert torch.equal(rec['texture_mask'].cpu(), mask)
-                tok_ref = R.segm_tokens(segm, sds['segm_encoder'], sds['segm_quant_conv'],
-                                        sds['segm_quantizer']['embedding.weight']).view(segm.shape[0], -1)
+                tok_ref = R.segm_tokens(odev(segm), od['segm_encoder'], od['segm_quant_conv'],
+                                        od['segm_quantizer']['embedding.weight']).view(segm.shape[0], -1).cpu()
                 checks.append(float((rec['segm_tokens'].cpu() != tok_ref).float().mean()))
                 tok = rec['segm_tokens']
             else:
                 mask = batch['texture_mask']
                 assert torch.equal(rec['texture_mask'].cpu(), mask)
-                tok_ref = R.segm_tokens(batch['segm'], sds['segm_encoder'], sds['segm_quant_conv'],
-                                        sds['segm_quantizer']['embedding.weight']).view(mask.shape[0], -1)
+                tok_ref = R.segm_tokens(odev(batch['segm']), od['segm_encoder'], od['segm_quant_conv'],
+                                        od['segm_quantizer']['embedding.weight']).view(mask.shape[0], -1).cpu()
                 assert torch.equal(rec['segm_tokens'].cpu(), tok_ref)      # piece-wise constant maps: exact
                 tok = tok_ref.to(DEV)
             top = R.sample_fn(tok, mask.to(DEV), sd_dev, sample_steps=STEPS, noise=R.TorchNoise(DEV))
             assert torch.equal(torch.stack(top), torch.stack(rec['top'])), (i, 'sampled tokens differ from the oracle')
-            img, _ = R.refine_and_decode([t.cpu() for t in top], mask, sds)
-            u8 = R.to_uint8(img).numpy()
+            img, _ = R.refine_and_decode(odev(top), odev(mask), od)
+            u8 = R.to_uint8(img).cpu().numpy()
             for j, n in enumerate(batch['img_name']):
                 assert n not in out
                 out[n] = u8[j]

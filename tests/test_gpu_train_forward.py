@@ -8,6 +8,8 @@ import torch.nn.functional as F
 from text2human_amd import defaults, ops, options, synthetic
 from text2human_amd.models import TransformerTextureAwareModel
 
+from parity_util import odev, osds  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
@@ -56,10 +58,12 @@ def test_train_loss_matches_oracle(loss_type):
     u = torch.rand(B, 512, generator=gen)
     loss, vb = model._train_loss(model.input_indices, model.gt_indices_list, t=t, u=u)
     with torch.no_grad():
-        _, top_idx = R.top_encode(image, batch['texture_mask'], sds)
+        od = osds(sds)   # (the oracle's encoders: parity_util.ORACLE_DEV; its transformer loss on the CPU)
+        _, top_idx = R.top_encode(odev(image), odev(batch['texture_mask']), od)
+        top_idx = odev(top_idx, 'cpu')
         tex = R.texture_tokens(batch['texture_mask'])
-        seg = R.segm_tokens(batch['segm'], sds['segm_encoder'], sds['segm_quant_conv'],
-                            sds['segm_quantizer']['embedding.weight']).view(B, -1)
+        seg = R.segm_tokens(odev(batch['segm']), od['segm_encoder'], od['segm_quant_conv'],
+                            od['segm_quantizer']['embedding.weight']).view(B, -1).cpu()
         gt_list = [i.view(B, -1) for i in top_idx]
         own = torch.stack(gt_list).gather(0, tex[None])[0]
         x_0 = own + 1024 * tex

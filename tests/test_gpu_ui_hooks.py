@@ -12,6 +12,8 @@ from oracle import torch_ref as R
 from text2human_amd import defaults, options, synthetic
 from text2human_amd.models import SampleFromPoseModel
 
+from parity_util import odev, osds  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
@@ -30,10 +32,12 @@ def test_ui_demo_call_order_vs_oracle():
     model.feed_shape_attributes(torch.LongTensor(pb['shape_attr'][0].tolist()).unsqueeze(0))
     model.generate_parsing_map()
     model.generate_quantized_segm()
+    od = osds(sds)   # (the oracle's convolutional stages: parity_util.ORACLE_DEV)
     with torch.no_grad():
-        ref_segm, _ = R.parsing_from_pose(pb['densepose'], pb['shape_attr'], sds['shape_embedder'],
-                                          sds['shape_encoder'], sds['shape_decoder'],
+        ref_segm, _ = R.parsing_from_pose(odev(pb['densepose']), odev(pb['shape_attr']), od['shape_embedder'],
+                                          od['shape_encoder'], od['shape_decoder'],
                                           opt['shape_attr_class_num'])
+    ref_segm = ref_segm.cpu()
     assert model.segm.shape == (1, 1, 512, 256) and model.segm.dtype == torch.int64
     agree = (model.segm.cpu() == ref_segm).float().mean().item()
     assert agree > 0.9999, f'parsing agrees on {agree:.6f} of the pixels'  # float near-ties only
@@ -61,11 +65,13 @@ def test_ui_demo_call_order_vs_oracle():
     finally:
         model.noise = None
     assert result.shape == (1, 3, 512, 256) and result.dtype == torch.float32
-    with torch.no_grad():
-        ref_img, inter = R.sample_from_parsing(ref_segm.float(), ref_mask, sds, sample_steps=4,
-                                               noise=R.SeededNoise(11, 'cpu'))
-    assert torch.equal(model.segm_tokens.cpu(), inter['segm_tokens'])
-    assert (result.cpu() - ref_img).abs().max().item() < 2e-4
+    with torch.no_grad():   # R.sample_from_parsing, its sampler on the CPU like the explicit noise it is given
+        tok = R.segm_tokens(odev(ref_segm.float()), od['segm_encoder'], od['segm_quant_conv'],
+                            od['segm_quantizer']['embedding.weight']).view(1, -1).cpu()
+        top = R.sample_fn(tok, ref_mask, sds['sampler'], 4, noise=R.SeededNoise(11, 'cpu'))
+        ref_img, _ = R.refine_and_decode(odev(top), odev(ref_mask), od)
+    assert torch.equal(model.segm_tokens.cpu(), tok)
+    assert (result.cpu() - ref_img.cpu()).abs().max().item() < 2e-4
     # what the UI does with it (ui_demo.py:162-167)
     out = np.asarray((result.permute(0, 2, 3, 1).detach().cpu().numpy() * 255)[0], dtype=np.uint8)
     assert out.shape == (512, 256, 3)

@@ -33,6 +33,7 @@ class GemmArgs(ctypes.Structure):
         ('stride', c_i32), ('pad', c_i32), ('ups', c_i32), ('batch', c_i32),
         ('strideA', c_i64), ('strideB', c_i64), ('strideC', c_i64),
         ('gn_part_out', c_vp),
+        ('splitk_ws', c_vp), ('splitk_ws_floats', c_i64), ('ksplit', c_i32),
     ]
 
 
@@ -86,9 +87,11 @@ SIGNATURES = {
     't2h_last_error': (ctypes.c_char_p, []),
     't2h_gemm_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp]),
     't2h_gemm_tile_config': (ctypes.c_int, [ctypes.POINTER(GemmArgs)]),
+    't2h_gemm_ksplit': (ctypes.c_int, [ctypes.POINTER(GemmArgs)]),
     't2h_conv_split_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp]),
     't2h_conv_halo_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp, c_vp]),
     't2h_conv_halo_force_variant': (ctypes.c_int, [ctypes.c_int]),
+    't2h_conv_halo_set_stagger': (ctypes.c_int, [ctypes.c_int]),
     't2h_gn_apply_split_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     't2h_gemm_force_config': (ctypes.c_int, [ctypes.c_int]),
     't2h_layernorm_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),

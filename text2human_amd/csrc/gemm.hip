@@ -115,6 +115,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
     n0 = (lin - mt * nbx) * BN;
   }
   const int64_t zb = blockIdx.y;
+  // split over K across workgroups (conv mode, small pixel counts: the deep levels of the index-prediction / parsing
+  // UNets, where M = images x a handful of pixels gives 8-32 tiles that each stream megabytes of weights): slice
+  // blockIdx.z of `ksplit` takes K tiles [kt_begin, kt_begin + nk) and stores its PARTIAL tile, unscaled, to
+  // splitk_ws[slice][M][N]; splitk_reduce_kernel sums the slices in slice order and applies the epilogue
+  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+  const int nk_all = p.K / BK;
+  const int kt_begin = (int)(((int64_t)blockIdx.z * nk_all) / ksplit);
+  const int nk = (int)(((int64_t)(blockIdx.z + 1) * nk_all) / ksplit) - kt_begin;
   const float* __restrict__ Ag = p.A + zb * p.strideA;
   const float* __restrict__ Bg = p.B + zb * p.strideB;
   float* __restrict__ Cg = p.C + zb * p.strideC;
@@ -157,9 +165,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
   struct TileK {  // wave-uniform description of K tile kt
     int k0, c0, dy, dx;
   };
-  auto tile_k = [&](int kt) {
+  auto tile_k = [&](int kt) {  // kt: K tile of THIS workgroup's slice
     TileK t;
-    t.k0 = kt * BK;
+    t.k0 = (kt + kt_begin) * BK;
     t.c0 = t.dy = t.dx = 0;
     if (AMODE == 1) {
       const int tap = t.k0 / p.Cin;
@@ -254,7 +262,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK;
   const int last = nk - 1;
 
   // MFMA work of one K tile out of LDS[buf]; `aux(s)` is called after MFMA step s.
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
     };
     auto issue = [&](auto setc, int kt) {  // all loads of tile kt into register set S
       constexpr int S = decltype(setc)::value;
-      const int k0 = min(kt, last) * BK;
+      const int k0 = (min(kt, last) + kt_begin) * BK;
 #pragma unroll
       for (int i = 0; i < B_F4; ++i) gload4_async(rb[S][i], b_src[i] + k0);
 #pragma unroll
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
     auto step = [&](int kt, auto setc) {  // set S holds tile kt+1
       constexpr int S = decltype(setc)::value;
       const int buf = kt & 1;
-      const int kn = min(kt + 3, last) * BK;
+      const int kn = (min(kt + 3, last) + kt_begin) * BK;
       mma_tile(buf, [&](int s) {
 #pragma unroll
         for (int q = 0; q < L; ++q) {
@@ -479,6 +486,22 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31,
   //      row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (ksplit > 1) {  // partial tile of this K slice, as accumulated
+    float* const W = p.splitk_ws + (int64_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TN; ++tj) {
+        const int col = n0 + wn0 + tj * 32 + l31;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (row < p.M) W[(int64_t)row * p.N + col] = acc[ti][tj][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti) {
 #pragma unroll
@@ -502,10 +525,27 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gemm_kernel(const t2h_
   }
 }
 
+// The slices of a K-split launch summed in slice order (fixed: bit-reproducible), then gemm_kernel's epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const t2h_gemm_args p, int ksplit) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t mn = (int64_t)p.M * p.N;
+  if (i >= mn) return;
+  const int row = (int)(i / p.N), col = (int)(i - (int64_t)row * p.N);
+  float a = p.splitk_ws[i];
+  for (int s = 1; s < ksplit; ++s) a += p.splitk_ws[s * mn + i];
+  float v = a * p.alpha + (p.bias ? p.bias[col] : 0.f);
+  const float rv = p.residual ? p.residual[(int64_t)row * p.ldr + col] : 0.f;
+  if (p.res_pre) v += rv;
+  if (p.epi_act == 1) v = gelu_erf(v);
+  else if (p.epi_act == 2) v = fmaxf(v, 0.f);
+  if (!p.res_pre) v += rv;
+  p.C[(int64_t)row * p.ldc + col] = v;
+}
+
 // ---- launch: every (tile, mode) combination
 template <int BM, int BN, int BK, int WARPS_M, int WARPS_N, bool FULL>
 int launch_cfg(const t2h_gemm_args& a, hipStream_t s) {
-  dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), a.batch);
+  dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), a.batch, a.ksplit > 1 ? a.ksplit : 1);
   dim3 block(64 * WARPS_M * WARPS_N);
   const bool pro = a.pro_scale != nullptr;
   const int rows_per_img = a.a_mode == 0 ? a.pro_rows : a.Hout * a.Wout;
@@ -532,6 +572,8 @@ int launch_cfg(const t2h_gemm_args& a, hipStream_t s) {
     }
   }
 #undef T2H_LAUNCH
+  if (a.ksplit > 1)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((int64_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, a, a.ksplit);
   T2H_CHECK_LAUNCH("t2h_gemm_f32");
   return T2H_OK;
 }
@@ -584,6 +626,21 @@ int pick_cfg(const t2h_gemm_args& a) {
   return CFG_128x64;
 }
 
+// K slices of a conv-mode launch, from (K, N, pixels per image) ONLY -- never from the number of images, so that an
+// image's values do not depend on the batch (or decode chunk) it is computed in: as many slices as give a NOMINAL batch
+// of 8 images (128 x 64 tiles) one workgroup per CU, at least four K tiles each, at most 32.
+int pick_ksplit(const t2h_gemm_args& a) {
+  if (a.a_mode != 1 || a.batch != 1 || !a.splitk_ws) return 1;
+  const int64_t rpi = (int64_t)a.Hout * a.Wout;
+  if (rpi > 512) return 1;
+  const int nk = a.K / 32;
+  const int64_t tiles8 = ((8 * rpi + 127) / 128) * ((a.N + 63) / 64);
+  int ks = (int)((256 + tiles8 - 1) / tiles8);
+  ks = ks < nk / 4 ? ks : nk / 4;
+  ks = ks < 32 ? ks : 32;
+  return ks > 1 ? ks : 1;
+}
+
 }  // namespace
 
 #ifdef T2H_GEMM_TIMING
@@ -625,7 +682,29 @@ extern "C" int t2h_gemm_f32(const t2h_gemm_args* args, void* stream) {
     T2H_REQUIRE(a.a_mode == 0, "t2h_gemm_f32: unknown a_mode %d", a.a_mode);
     if (a.b_trans) T2H_REQUIRE(a.N % 4 == 0, "t2h_gemm_f32: b_trans needs N %% 4 == 0");
   }
+  T2H_REQUIRE(a.ksplit >= 0 && a.ksplit <= 64, "t2h_gemm_f32: ksplit=%d (0 = automatic, <= 64)", a.ksplit);
+  if (a.ksplit == 0) a.ksplit = pick_ksplit(a);
+  if (a.ksplit > 1) {
+    T2H_REQUIRE(a.batch == 1 && a.splitk_ws && a.ksplit <= a.K / 64,
+                "t2h_gemm_f32: ksplit=%d needs batch 1, a workspace and at least 64 of K per slice (K=%d)", a.ksplit, a.K);
+    if ((int64_t)a.ksplit * a.M * a.N > a.splitk_ws_floats) {
+      T2H_REQUIRE(args->ksplit == 0, "t2h_gemm_f32: ksplit=%d needs a workspace of %lld floats (given %lld)", a.ksplit,
+                  (long long)a.ksplit * a.M * a.N, (long long)a.splitk_ws_floats);
+      // (automatic: the slice count must not depend on the batch, so a workspace that is too small for this batch is
+      // an error of the caller's sizing, not a reason to compute differently)
+      t2h_set_error("t2h_gemm_f32: the split-K workspace holds %lld floats, this launch needs %lld (ksplit %d x M %d x N %d)",
+                    (long long)a.splitk_ws_floats, (long long)a.ksplit * a.M * a.N, a.ksplit, a.M, a.N);
+      return T2H_ERR_INVALID;
+    }
+  }
   return launch_by_cfg(pick_cfg(a), a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t2h_gemm_ksplit(const t2h_gemm_args* args) {
+  if (!args) return -1;
+  t2h_gemm_args a = *args;
+  if (a.batch < 1) a.batch = 1;
+  return a.ksplit > 0 ? a.ksplit : pick_ksplit(a);
 }
 
 extern "C" int t2h_gemm_tile_config(const t2h_gemm_args* args) {

@@ -99,6 +99,8 @@ def gemm_profile_active():
     return _prof is not None
 
 
+_HALO_STAGGER = int(os.environ.get('T2H_HALO_STAGGER', '0'))  # (A/B switch of the halo convolution's staggered start)
+_SPLITK = os.environ.get('T2H_CONV_SPLITK', '1') != '0'  # (A/B switch of the exact-fp32 convolutions' split over K)
 SPLIT_CFG_NAMES = {0: '128x64', 1: '128x128', 2: '64x64', 3: '128x64, 8 waves', 5: '128x256', 6: '128x64, 2 K groups',
                    8: '256x128, ping-pong LDS-DMA', 9: 'few rows (16x16 per workgroup, K over 8 waves)',
                    10: '128x192, ping-pong LDS-DMA', 11: '128x128, ping-pong LDS-DMA'}
@@ -325,6 +327,8 @@ def conv_halo(x, w_split, n_img, hin, win, cin, cout, out=None, bias=None, resid
         part = torch.empty((n_img, hout * wout // 128, 2, cout), device=x.device, dtype=torch.float64)
         g.gn_part_out = part.data_ptr()
     lib = _lib.load()
+    if _HALO_STAGGER:   # (experiment; the hook is thread-local, so it is set by the launching thread)
+        lib.t2h_conv_halo_set_stagger(_HALO_STAGGER)
     flops = 2.0 * M * cout * 9 * cin
     if _prof is not None:
         _prof['count'] += 1
@@ -395,6 +399,15 @@ def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=
         _chk_f32(sc, sh)
         g.pro_scale, g.pro_shift = sc.data_ptr(), sh.data_ptr()
         g.pro_ld, g.pro_act = sc.shape[1], pact
+    # few pixels per image (the deep UNet levels): K split across workgroups, partial tiles in a workspace of this
+    # call (stream-ordered like every torch allocation); the slice count depends on the layer's geometry only
+    if _SPLITK:
+        g.splitk_ws = ctypes.c_void_p(1)  # (non-NULL: ask what the library would do with a workspace)
+        ks = _lib.load().t2h_gemm_ksplit(ctypes.byref(g))
+        g.splitk_ws = None
+        if ks > 1:
+            ws = torch.empty(ks * M * N, device=x.device, dtype=torch.float32)
+            g.splitk_ws, g.splitk_ws_floats = ws.data_ptr(), ws.numel()
     _launch_gemm(g, 't2h_gemm_f32(conv)')
     return out
 

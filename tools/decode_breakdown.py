@@ -62,7 +62,15 @@ def summarize(db_path, out_path, n_dec):
     db = sqlite3.connect(db_path)
     cols = [r[1] for r in db.execute('pragma table_info(kernels)')]
     grid = 'grid_size' if 'grid_size' in cols else ('grid_x * grid_y * grid_z' if 'grid_x' in cols else '0')
-    rows = list(db.execute(f'select name, {grid}, count(*), sum(duration), avg(duration) from kernels group by name, {grid}'))
+    # only what lies between the FIRST and the LAST decode's image epilogue (one per decode): the model's construction
+    # (weight packing, the x8 calibration of the sampler) and the first decode's warm-up are not the stage's
+    ts = 'start' if 'start' in cols else 'start_timestamp'
+    marks = [r[0] for r in db.execute(f"select {ts} from kernels where name like '%image_epilogue%' order by {ts}")]
+    assert marks and len(marks) % n_dec == 0, (len(marks), n_dec)  # (a chunked decode has one epilogue per chunk)
+    marks = marks[len(marks) // n_dec - 1:]
+    n_dec -= 1
+    rows = list(db.execute(f'select name, {grid}, count(*), sum(duration), avg(duration) from kernels '
+                           f'where {ts} > {marks[0]} and {ts} <= {marks[-1]} group by name, {grid}'))
     total = sum(r[3] for r in rows)
     by_role, detail = {}, []
     for name, gsz, n, tot, avg in rows:
@@ -74,7 +82,7 @@ def summarize(db_path, out_path, n_dec):
         detail.append((tot, k, gsz, n, avg, role))
     import bench
     out = [f'# refine + decode of one batch: per-kernel account\n\nsource: `{db_path}` (rocprofv3 --kernel-trace over '
-           f'`tools/decode_breakdown.py run`: {n_dec} decodes, nothing else on the GPU); kernel sources {bench.kernel_src_digest()}; '
+           f'`tools/decode_breakdown.py run`: {n_dec + 1} decodes, the first left out, nothing else on the GPU); kernel sources {bench.kernel_src_digest()}; '
            f'kernel time per decode {total / n_dec / 1e6:.2f} ms\n\n## by role (per decode of the batch)\n\n'
            '| role | launches | us | % |\n|---|---:|---:|---:|']
     for role, (n, tot) in sorted(by_role.items(), key=lambda kv: -kv[1][1]):
