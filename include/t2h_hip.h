@@ -131,10 +131,6 @@ int t2h_conv_split_f32(const t2h_gemm_args* args, void* stream);
  * with tables, an image and the weights < 2 GiB each. */
 int t2h_conv_halo_f32(const t2h_gemm_args* args, int32_t* overflow_flag, void* stream);
 int t2h_conv_halo_force_variant(int v); /* tuning / tests (thread-local): 1 = LDS-DMA weight tiles, two fragment sets, staged conversion (default); 0 = the first, register-staged kernel; returns the old value */
-/* experiment of round 6 (thread-local, 0 = off, the default; 2..8): the CUs' first workgroups of a launch of >= 1024
- * workgroups start `populations` fractions of a tile apart, so that the HBM bursts of the prologues / epilogues of one
- * population meet the main loops of the others; the values computed do not change; returns the old value */
-int t2h_conv_halo_set_stagger(int populations);
 /* 3x3 'same' convolution with 1..4 output channels (the decoders' conv_out, vqgan_arch.py:997,1026-1033) on
  * the vector ALU, exact fp32: out[pixel][co] = bias[co] + sum over taps, channels of
  * act(x * scale[img] + shift[img]) * w[co][tap][c] (scale NULL = no prologue; act 1 = swish), zero padding of

@@ -119,6 +119,35 @@ def test_conv3x3(mode, cin, cout, h, w):
         assert_close(out, ref_rows, what=f'{mode} pro={use_pro}')
 
 
+@pytest.mark.parametrize('cin,cout,h,w', [(512, 1024, 2, 1), (1024, 512, 4, 2), (256, 256, 16, 8), (64, 64, 32, 16)])
+def test_conv3x3_split_over_k_at_the_deep_unet_levels(cin, cout, h, w):
+    """unet_arch.py:470-481,657-674: the index-prediction / parsing UNets' deep levels are a handful of pixels per image
+    against K = 9 * 512 .. 9 * 1024 -- t2h_gemm_f32 splits K across workgroups there (t2h_gemm_args.ksplit, round 6).
+    Against fp64; no further from it than the single pass; an image's values do not depend on its batch (the slice
+    count is a function of the layer's geometry only) -- bit for bit."""
+    from text2human_amd import _lib, weights
+    n_img = 8
+    x = rnd(n_img, cin, h, w, seed=51)
+    wt, b = rnd(cout, cin, 3, 3, seed=52, scale=(9 * cin) ** -0.5), rnd(cout, seed=53)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), 1, 1)).permute(0, 2, 3, 1).reshape(-1, cout)
+    rows = ops.nchw_to_nhwc(x.to(DEV))
+    wp = weights.pack_conv3x3(wt).to(DEV)
+    auto = ops.conv3x3(rows, wp, n_img, h, w, cin, bias=b.to(DEV), act=ops.ACT_RELU)
+    one = ops.conv3x3(rows, wp, n_img, h, w, cin, bias=b.to(DEV), act=ops.ACT_RELU, ksplit=1)
+    forced = ops.conv3x3(rows, wp, n_img, h, w, cin, bias=b.to(DEV), act=ops.ACT_RELU, ksplit=3)
+    g = _lib.GemmArgs()
+    g.M, g.N, g.K, g.a_mode, g.batch, g.Hout, g.Wout, g.Cin = n_img * h * w, cout, 9 * cin, 1, 1, h, w, cin
+    import ctypes
+    g.splitk_ws = ctypes.c_void_p(1)
+    assert _lib.load().t2h_gemm_ksplit(ctypes.byref(g)) > 1      # these geometries ARE split
+    e_auto, e_one = (auto.cpu().double() - ref).abs().max().item(), (one.cpu().double() - ref).abs().max().item()
+    assert_close(auto, ref, what='split over K')
+    assert_close(forced, ref, what='3 slices')
+    assert e_auto <= e_one + 1e-6, (e_auto, e_one)
+    alone = ops.conv3x3(rows[:h * w].contiguous(), wp, 1, h, w, cin, bias=b.to(DEV), act=ops.ACT_RELU)
+    assert torch.equal(alone, auto[:h * w]), 'an image depends on its batch'
+
+
 def test_conv3x3_channel_padding_and_relu_prebias():
     from text2human_amd import weights
     n_img, cin, cout, h, w = 2, 24, 64, 16, 16

@@ -91,7 +91,6 @@ SIGNATURES = {
     't2h_conv_split_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp]),
     't2h_conv_halo_f32': (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_vp, c_vp]),
     't2h_conv_halo_force_variant': (ctypes.c_int, [ctypes.c_int]),
-    't2h_conv_halo_set_stagger': (ctypes.c_int, [ctypes.c_int]),
     't2h_gn_apply_split_f32': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     't2h_gemm_force_config': (ctypes.c_int, [ctypes.c_int]),
     't2h_layernorm_f32': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),

@@ -540,7 +540,7 @@ constexpr int CH_TAB_OFF = CH_DMA_LOOP_B + CH_DUMMY_B;
 static_assert(CH_TAB_OFF % 16 == 0, "table alignment");
 
 template <int PRO>
-__global__ __launch_bounds__(CH_NT, 2) void conv_halo_dma_kernel(const t2h_gemm_args p, int* ovf, const int stagger HALO_PROBE_ARG) {
+__global__ __launch_bounds__(CH_NT, 2) void conv_halo_dma_kernel(const t2h_gemm_args p, int* ovf HALO_PROBE_ARG) {
   constexpr int TM = CH_TM, TN = CH_TN;
   constexpr int TAB_B = PRO ? 2 * 512 * 4 : 0;  // scale[Cin] | shift[Cin] of this image (Cin <= 512, host-checked)
   constexpr int SMEM_B = CH_EPI_B > CH_TAB_OFF + TAB_B ? CH_EPI_B : CH_TAB_OFF + TAB_B;
@@ -565,19 +565,6 @@ __global__ __launch_bounds__(CH_NT, 2) void conv_halo_dma_kernel(const t2h_gemm_
 
   const char* const a_img = reinterpret_cast<const char*>(p.A + (int64_t)q.img * p.Hin * p.Win * p.lda);  // scalar
   float amax = 0.f;
-
-  // ---- staggered start (experiment of round 6, t2h_conv_halo_set_stagger; off by default): with one workgroup per CU
-  // (154 KB of LDS) and equal tiles, all 256 CUs reach their prologue (first halo from HBM) and their epilogue (128 KiB
-  // out + 128 KiB residual in) at the same moment, 16 times per launch at the top level -- 22 % of a workgroup's time
-  // are these bursts.  The FIRST workgroup of a CU (the first 256 of the grid) waits pop / stagger of a tile's duration,
-  // pop = its slot inside the XCD modulo `stagger`: the CUs then walk their tiles in `stagger` populations a fraction
-  // of a tile apart, and a population's bursts meet the other populations' main loops.
-  if (stagger > 1 && blockIdx.x < 256 && gridDim.x >= 1024) {
-    const int pop = ((int)blockIdx.x >> 3) % stagger;
-    const long long wait = ((long long)nk * 2100 + 21000) * pop / stagger;   // (shader cycles: 36 K tiles -> 96 k)
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    for (int it = 0; it < 4096 && (long long)__builtin_amdgcn_s_memtime() - t0 < wait; ++it) __builtin_amdgcn_s_sleep(16);
-  }
 
   // ---- weight tile requests of this wave: 8-row groups uwave and uwave + 8 of the 128-row tile image; lane -> row
   // 8 grp + lane / 8, physical piece lane % 8 = logical piece (lane % 8) ^ ((row >> 1) & 7)
@@ -899,7 +886,6 @@ __global__ __launch_bounds__(CH_NT, 2) void conv_halo_dma_kernel(const t2h_gemm_
 }
 
 thread_local int g_halo_variant = 1;  // tuning / test hook of the calling thread
-thread_local int g_halo_stagger = 0;  // (experiment: t2h_conv_halo_set_stagger)
 #ifdef T2H_HALO_PROBE
 thread_local long long* g_halo_probe = nullptr;
 #define HALO_PROBE_PASS , g_halo_probe
@@ -912,12 +898,6 @@ thread_local long long* g_halo_probe = nullptr;
 extern "C" int t2h_conv_halo_force_variant(int v) {
   const int old = g_halo_variant;
   g_halo_variant = v == 0 ? 0 : 1;
-  return old;
-}
-
-extern "C" int t2h_conv_halo_set_stagger(int populations) {
-  const int old = g_halo_stagger;
-  g_halo_stagger = populations > 1 && populations <= 8 ? populations : 0;
   return old;
 }
 
@@ -962,8 +942,8 @@ extern "C" int t2h_conv_halo_f32(const t2h_gemm_args* args, int32_t* overflow_fl
     if (pro) hipLaunchKernelGGL(conv_halo_reg_kernel<2>, grid, block, 0, s, a, overflow_flag);
     else hipLaunchKernelGGL(conv_halo_reg_kernel<0>, grid, block, 0, s, a, overflow_flag);
   } else {
-    if (pro) hipLaunchKernelGGL(conv_halo_dma_kernel<2>, grid, block, 0, s, a, overflow_flag, g_halo_stagger HALO_PROBE_PASS);
-    else hipLaunchKernelGGL(conv_halo_dma_kernel<0>, grid, block, 0, s, a, overflow_flag, g_halo_stagger HALO_PROBE_PASS);
+    if (pro) hipLaunchKernelGGL(conv_halo_dma_kernel<2>, grid, block, 0, s, a, overflow_flag HALO_PROBE_PASS);
+    else hipLaunchKernelGGL(conv_halo_dma_kernel<0>, grid, block, 0, s, a, overflow_flag HALO_PROBE_PASS);
   }
   T2H_CHECK_LAUNCH("t2h_conv_halo_f32");
   return T2H_OK;

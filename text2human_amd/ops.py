@@ -99,7 +99,6 @@ def gemm_profile_active():
     return _prof is not None
 
 
-_HALO_STAGGER = int(os.environ.get('T2H_HALO_STAGGER', '0'))  # (A/B switch of the halo convolution's staggered start)
 _SPLITK = os.environ.get('T2H_CONV_SPLITK', '1') != '0'  # (A/B switch of the exact-fp32 convolutions' split over K)
 SPLIT_CFG_NAMES = {0: '128x64', 1: '128x128', 2: '64x64', 3: '128x64, 8 waves', 5: '128x256', 6: '128x64, 2 K groups',
                    8: '256x128, ping-pong LDS-DMA', 9: 'few rows (16x16 per workgroup, K over 8 waves)',
@@ -327,8 +326,6 @@ def conv_halo(x, w_split, n_img, hin, win, cin, cout, out=None, bias=None, resid
         part = torch.empty((n_img, hout * wout // 128, 2, cout), device=x.device, dtype=torch.float64)
         g.gn_part_out = part.data_ptr()
     lib = _lib.load()
-    if _HALO_STAGGER:   # (experiment; the hook is thread-local, so it is set by the launching thread)
-        lib.t2h_conv_halo_set_stagger(_HALO_STAGGER)
     flops = 2.0 * M * cout * 9 * cin
     if _prof is not None:
         _prof['count'] += 1
@@ -365,12 +362,14 @@ def bgemm(a, w, out, alpha=1.0, b_trans=False):
 
 
 def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=ACT_NONE,
-            pro=None, mode='same', res_pre=False):
+            pro=None, mode='same', res_pre=False, ksplit=None):
     """3x3 convolution of an NHWC image held as pixel rows x [n_img*hin*win, >=cin]
     with packed weights w [Cout, 9*cin] ([tap][cin] order).
 
     mode: 'same' (stride 1 pad 1), 'up' (nearest x2 then same conv),
-          'down' (zero-pad right/bottom by 1, stride 2)."""
+          'down' (zero-pad right/bottom by 1, stride 2).
+    ksplit: K slices on their own workgroups (t2h_gemm_args.ksplit): None = the library's choice from the layer's
+          geometry (few pixels per image: the deep UNet levels), 1 = one pass over K, n > 1 = n slices."""
     _chk_f32(x, w, out, bias, residual)
     if mode == 'same':
         hout, wout, stride, pad, ups = hin, win, 1, 1, 0
@@ -401,13 +400,15 @@ def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=
         g.pro_ld, g.pro_act = sc.shape[1], pact
     # few pixels per image (the deep UNet levels): K split across workgroups, partial tiles in a workspace of this
     # call (stream-ordered like every torch allocation); the slice count depends on the layer's geometry only
-    if _SPLITK:
+    if ksplit is None and _SPLITK:
         g.splitk_ws = ctypes.c_void_p(1)  # (non-NULL: ask what the library would do with a workspace)
-        ks = _lib.load().t2h_gemm_ksplit(ctypes.byref(g))
+        ksplit = _lib.load().t2h_gemm_ksplit(ctypes.byref(g))
         g.splitk_ws = None
-        if ks > 1:
-            ws = torch.empty(ks * M * N, device=x.device, dtype=torch.float32)
-            g.splitk_ws, g.splitk_ws_floats = ws.data_ptr(), ws.numel()
+    if ksplit is not None and ksplit > 1:
+        ws = torch.empty(ksplit * M * N, device=x.device, dtype=torch.float32)
+        g.splitk_ws, g.splitk_ws_floats, g.ksplit = ws.data_ptr(), ws.numel(), int(ksplit)
+    else:
+        g.ksplit = 1
     _launch_gemm(g, 't2h_gemm_f32(conv)')
     return out
 
