@@ -336,13 +336,14 @@ extern "C" int t2h_tap_bias_map_f32(const float* tapc, float* out, int32_t B, in
 // independent, hence deterministic.  Used once per checkpoint (engine.SamplerNet.calibrate_x8: the scales of the x8
 // format's 8-bit planes), never on the sampling path.  NaN / inf propagate as a huge bit pattern (the caller checks).
 __global__ void absmax_f32_kernel(const float* __restrict__ x, int ldx, int C, int64_t total, unsigned* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float m = 0.f;
-  if (i < total) {
+  // (grid-stride: at most 256 workgroups, one atomic per wave -- a single word takes ~88 atomics per microsecond, and one
+  // per wave of a 4 M-element tensor made this a 745 us kernel)
+  unsigned b = 0u;  // (the maximum is taken on the bit patterns of |x|: monotonic for non-negative floats, NaN above all)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / C;
-    m = fabsf(x[r * ldx + (i - r * C)]);
+    const unsigned t = __builtin_bit_cast(unsigned, fabsf(x[r * ldx + (i - r * C)]));
+    b = t > b ? t : b;
   }
-  unsigned b = __builtin_bit_cast(unsigned, m);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned t = (unsigned)__shfl_xor((int)b, o, 64);
@@ -353,10 +354,11 @@ __global__ void absmax_f32_kernel(const float* __restrict__ x, int ldx, int C, i
 
 // the same over the fp16 hi plane of split rows / x8 rows [rows][C/32][128 bytes]: the first 64 bytes of a tile
 __global__ void split_rows_absmax_kernel(const uint16_t* __restrict__ sp, int64_t total, unsigned* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // element of the hi planes: tile i / 32, k i % 32
-  float m = 0.f;
-  if (i < total) m = fabsf((float)reinterpret_cast<const _Float16*>(sp)[(i >> 5) * 64 + (i & 31)]);
-  unsigned b = __builtin_bit_cast(unsigned, m);
+  unsigned b = 0u;  // element i of the hi planes: tile i / 32, k i % 32
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned t = __builtin_bit_cast(unsigned, fabsf((float)reinterpret_cast<const _Float16*>(sp)[(i >> 5) * 64 + (i & 31)]));
+    b = t > b ? t : b;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned t = (unsigned)__shfl_xor((int)b, o, 64);
@@ -394,8 +396,9 @@ extern "C" int t2h_gather_rows(const void* src, const int32_t* rows, void* dst, 
 extern "C" int t2h_absmax_f32(const float* x, int32_t ldx, int64_t rows, int32_t C, uint32_t* out_bits, void* stream) {
   T2H_REQUIRE(x && out_bits && rows > 0 && C > 0 && ldx >= C, "t2h_absmax_f32: bad arguments");
   const int64_t total = rows * C;
-  hipLaunchKernelGGL(absmax_f32_kernel, grid1d(total), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, C, total,
-                     out_bits);
+  dim3 grid = grid1d(total);
+  grid.x = grid.x < 256u ? grid.x : 256u;
+  hipLaunchKernelGGL(absmax_f32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, C, total, out_bits);
   T2H_CHECK_LAUNCH("t2h_absmax_f32");
   return T2H_OK;
 }
@@ -403,8 +406,9 @@ extern "C" int t2h_absmax_f32(const float* x, int32_t ldx, int64_t rows, int32_t
 extern "C" int t2h_split_rows_absmax(const uint16_t* rows_split, int64_t rows, int32_t C, uint32_t* out_bits, void* stream) {
   T2H_REQUIRE(rows_split && out_bits && rows > 0 && C > 0 && C % 32 == 0, "t2h_split_rows_absmax: bad arguments");
   const int64_t total = rows * C;
-  hipLaunchKernelGGL(split_rows_absmax_kernel, grid1d(total), dim3(256), 0, static_cast<hipStream_t>(stream), rows_split,
-                     total, out_bits);
+  dim3 grid = grid1d(total);
+  grid.x = grid.x < 256u ? grid.x : 256u;
+  hipLaunchKernelGGL(split_rows_absmax_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), rows_split, total, out_bits);
   T2H_CHECK_LAUNCH("t2h_split_rows_absmax");
   return T2H_OK;
 }
