@@ -99,7 +99,6 @@ def gemm_profile_active():
     return _prof is not None
 
 
-_SPLITK = os.environ.get('T2H_CONV_SPLITK', '1') != '0'  # (A/B switch of the exact-fp32 convolutions' split over K)
 SPLIT_CFG_NAMES = {0: '128x64', 1: '128x128', 2: '64x64', 3: '128x64, 8 waves', 5: '128x256', 6: '128x64, 2 K groups',
                    8: '256x128, ping-pong LDS-DMA', 9: 'few rows (16x16 per workgroup, K over 8 waves)',
                    10: '128x192, ping-pong LDS-DMA', 11: '128x128, ping-pong LDS-DMA'}
@@ -400,7 +399,7 @@ def conv3x3(x, w, n_img, hin, win, cin, out=None, bias=None, residual=None, act=
         g.pro_ld, g.pro_act = sc.shape[1], pact
     # few pixels per image (the deep UNet levels): K split across workgroups, partial tiles in a workspace of this
     # call (stream-ordered like every torch allocation); the slice count depends on the layer's geometry only
-    if ksplit is None and _SPLITK:
+    if ksplit is None:
         g.splitk_ws = ctypes.c_void_p(1)  # (non-NULL: ask what the library would do with a workspace)
         ksplit = _lib.load().t2h_gemm_ksplit(ctypes.byref(g))
         g.splitk_ws = None

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (ran on the tree of commit 7353688 where the A/B switch T2H_CONV_SPLITK still existed; it was removed with the round's
+# closing commit -- ops.conv3x3(ksplit=1) is the single-pass form -- so the second pass below now repeats the first)
 # Round-6 batch B: where the oracle's time goes (CPU vs eager ROCm), the decode account with / without the exact-fp32
 # convolutions' split over K, and the parity tests the split touches.  -> gpurun_out/r06b/
 set -u
