@@ -1,7 +1,7 @@
 """A/B of the attention kernel's softmax arithmetic (round 6): the product source built twice in the
 build container (tools/build_mha_ab.sh): tools/_tb/mha_base.so (-DT2H_MHA_PACKED=0) and tools/_tb/mha_packed.so (=1: the
 exponent arguments and the row sum on register pairs, v_pk_fma_f32 / v_pk_add_f32).  Same inputs, interleaved timing
-(alternating blocks of 40 launches, 12 blocks), x8 output like the product path; the outputs are compared.  GPU only.
+(alternating blocks of 40 launches, 12 blocks; a third build, mha_early.so = -DT2H_MHA_EARLY_S=1, joins when present), x8 output like the product path; the outputs are compared.  GPU only.
 
     python tools/mha_packed_ab.py [batch=8]
 """
@@ -22,7 +22,8 @@ ovf = torch.zeros(1, dtype=torch.int32, device='cuda')
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 libs, outs = {}, {}
-for name in ('base', 'packed'):
+VARIANTS = tuple(v for v in ('base', 'packed', 'early') if os.path.exists(os.path.join(ROOT, 'tools', '_tb', f'mha_{v}.so')))
+for name in VARIANTS:
     libs[name] = ctypes.CDLL(os.path.join(ROOT, 'tools', '_tb', f'mha_{name}.so'))
     libs[name].t2h_mha_split_x8_f32.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
@@ -34,7 +35,7 @@ for n in libs:
 torch.cuda.synchronize()
 times = {n: [] for n in libs}
 for blk in range(12):
-    for n in (('base', 'packed') if blk % 2 == 0 else ('packed', 'base')):
+    for n in (VARIANTS if blk % 2 == 0 else VARIANTS[::-1]):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(40):
@@ -44,7 +45,9 @@ for blk in range(12):
         times[n].append(e0.elapsed_time(e1) / 40 * 1e3)
 for n in libs:
     print(f'B={B} {n:7s}: median {statistics.median(times[n]):6.2f} us  [min {min(times[n]):.2f}, max {max(times[n]):.2f}] over 12 blocks of 40 launches')
-a, b = outs['base'].view(torch.uint8).cpu(), outs['packed'].view(torch.uint8).cpu()
 hi = lambda t: t.view(-1, 128)[:, :64].contiguous().view(torch.float16).float()
-d = (hi(a) - hi(b)).abs()
-print(f'outputs: {int((a != b).sum())} of {a.numel()} bytes differ; fp16 hi plane max |diff| {d.max().item():.3e} on values up to {hi(a).abs().max().item():.3f}')
+a = outs['base'].view(torch.uint8).cpu()
+for v in VARIANTS[1:]:
+    b = outs[v].view(torch.uint8).cpu()
+    d = (hi(a) - hi(b)).abs()
+    print(f'{v} vs base: {int((a != b).sum())} of {a.numel()} bytes differ; fp16 hi plane max |diff| {d.max().item():.3e} on values up to {hi(a).abs().max().item():.3f}')
