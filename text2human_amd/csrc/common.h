@@ -103,7 +103,9 @@ __device__ __forceinline__ float fast_exp(float x) {
 // to overlap -- although no other XCD can use that copy; sc1 sends the bytes out during the epilogue.
 // Measured on the fc1 shape (33.5 MB of split rows): 35.7 -> 33.0 us per launch, q|k|v 29.4 -> 28.1
 // (profiles/r02_store_flavour.log).  NOT for the fp32 residual stream, which proj / fc2 read and
-// rewrite in place: there sc1 costs +1.5-2 us.
+// rewrite in place: there sc1 costs +1.5-2 us.  Re-measured in round 6 on the whole B = 8 sampler with one kernel
+// file at a time on plain stores (profiles/r06_ln_xcd_ab.log): LayerNorm output +1.4 %, attention output +-0, the
+// GEMM epilogues' split rows / Vt planes +4.5 % -- write-through stays.
 template <typename V>
 __device__ __forceinline__ void t2h_store16_wt(void* ptr, const V& v) {
   static_assert(sizeof(V) == 16, "16-byte vector");

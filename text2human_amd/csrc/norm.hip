@@ -7,6 +7,9 @@ namespace {
 // (mean, then centred variance) like torch's rowwise moments.
 // SPLIT: the result is written as split rows (two fp16 planes) for the
 // split-precision GEMM instead of fp32.
+#ifndef T2H_LN_XCD
+#define T2H_LN_XCD 1  // (0: rows handed out round-robin, the mapping until round 6 -- the A/B build of tools/build_ln_xcd.sh)
+#endif
 #ifndef T2H_LN_RPB
 #define T2H_LN_RPB 8  // rows (= waves) per workgroup: with the input just written by the previous kernel,
                       // 6.3 us at 8 against 7.3 at 4, 6.6 at 2 / 16 (tools/ln_block_bench.py)
@@ -20,7 +23,21 @@ __global__ __launch_bounds__(64 * T2H_LN_RPB) void layernorm_kernel(const float*
                                                         float eps, int* ovf, float x8_scale = 1.0f) {
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * T2H_LN_RPB + (threadIdx.x >> 6);
+  // Workgroup -> rows, XCD-aware (round 6).  Workgroup b runs on XCD b % 8; the GEMM that wrote x gives XCD i the i-th
+  // eighth of its row blocks (gemm_split.hip / gemm.hip tile mapping), and its plain stores stay in that XCD's L2 across
+  // the kernel boundary.  With rows handed out round-robin every read missed (FETCH_SIZE = the whole tensor,
+  // profiles/r06_pmc_summary.md); with XCD i normalising the i-th eighth of the row blocks the proj GEMM + LayerNorm
+  // pair takes 18.1-19.6 instead of 21.1-21.3 us at M = 4096, 41.4 instead of 43.3 at M = 16384, same bits
+  // (profiles/r06_ln_xcd_ab.log).  Bijective for any workgroup count; a speed choice only.
+  int blk = blockIdx.x;
+#if T2H_LN_XCD
+  {
+    const int total = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3, q = total >> 3, r = total & 7;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+#endif
+  const int row = blk * T2H_LN_RPB + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (int64_t)row * C;
   f32x4 v[VPL];
