@@ -24,11 +24,13 @@ __global__ __launch_bounds__(64 * T2H_LN_RPB) void layernorm_kernel(const float*
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
   // Workgroup -> rows, XCD-aware (round 6).  Workgroup b runs on XCD b % 8; the GEMM that wrote x gives XCD i the i-th
-  // eighth of its row blocks (gemm_split.hip / gemm.hip tile mapping), and its plain stores stay in that XCD's L2 across
-  // the kernel boundary.  With rows handed out round-robin every read missed (FETCH_SIZE = the whole tensor,
-  // profiles/r06_pmc_summary.md); with XCD i normalising the i-th eighth of the row blocks the proj GEMM + LayerNorm
-  // pair takes 18.1-19.6 instead of 21.1-21.3 us at M = 4096, 41.4 instead of 43.3 at M = 16384, same bits
-  // (profiles/r06_ln_xcd_ab.log).  Bijective for any workgroup count; a speed choice only.
+  // eighth of its row blocks (gemm_split.hip / gemm.hip tile mapping).  With XCD i also normalising the i-th eighth of
+  // the row blocks a [proj GEMM -> LayerNorm] chain takes 18.1-19.6 instead of 21.1-21.3 us per pair at M = 4096 (41.4
+  // vs 43.3 at M = 16384) and the whole B = 8 sampler 1 % less over five interleaved pairs of runs, same bits
+  // (profiles/r06_ln_xcd_ab.log).  NOT because the rows are found in that XCD's L2: FETCH_SIZE is the whole tensor under
+  // either mapping (no line survives the kernel boundary), and the kernel's own duration barely moves (5.0 vs 5.4 us
+  // under the counters) -- what shortens is the hand-over between the two kernels.  Bijective for any workgroup count;
+  // a speed choice only.
   int blk = blockIdx.x;
 #if T2H_LN_XCD
   {
