@@ -14,7 +14,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _memoise_synthetic_weights(limit_bytes=10 << 30):
+    """Two dozen tests build the same synthetic checkpoints (text2human_amd.synthetic.make_state_dicts: 3-5 s of CPU
+    random numbers per call): one module's tensors are generated once per (schema, seed) and session and handed out as a
+    FRESH dict of the SAME tensors -- the tests replace entries, none writes into a tensor (a test that did would have
+    to clone first)."""
+    from collections import OrderedDict
+
+    from text2human_amd import synthetic
+    real, cache, held = synthetic.fill, {}, [0]
+
+    def fill(schema, seed):
+        try:
+            key = (int(seed), tuple(schema.items()))
+            hash(key)
+        except TypeError:
+            return real(schema, seed)
+        hit = cache.get(key)
+        if hit is None:
+            hit = real(schema, seed)
+            size = sum(t.numel() * t.element_size() for t in hit.values())
+            if held[0] + size <= limit_bytes:
+                cache[key] = hit
+                held[0] += size
+        return OrderedDict(hit)
+
+    synthetic.fill = fill
+
+
 def pytest_configure(config):
+    _memoise_synthetic_weights()
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
     config.addinivalue_line('markers', 'reference: needs /root/reference (build container only)')
 
