@@ -118,7 +118,7 @@ def test_emulated_conv_split_over_k_for_the_deep_unet_levels(gemm):
     and inside a batch gives the same bits."""
     gemm.t2h_gemm_ksplit.restype = ctypes.c_int
     gemm.t2h_gemm_ksplit.argtypes = [ctypes.POINTER(GemmArgs)]
-    n_img, cin, cout, h, w = 3, 64, 72, 4, 2
+    n_img, cin, cout, h, w = 2, 32, 40, 4, 2
     x = rnd(n_img, cin, h, w, seed=31)
     wt, b = rnd(cout, cin, 3, 3, seed=32, scale=0.1), rnd(cout, seed=33)
     ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), 1, 1)).permute(0, 2, 3, 1).reshape(-1, cout)
@@ -141,9 +141,9 @@ def test_emulated_conv_split_over_k_for_the_deep_unet_levels(gemm):
         return rc, ks, out
 
     rc, ks_auto, out_auto = run(n_img, 0)
-    assert rc == 0 and ks_auto == 4, (rc, ks_auto, gemm.emu_last_error())  # K = 576: 18 K tiles, at least four per slice
+    assert rc == 0 and ks_auto == 2, (rc, ks_auto, gemm.emu_last_error())  # K = 288: 9 K tiles, at least four per slice
     close(out_auto, ref + res.double())
-    for ks in (1, 3, 9):   # no split; slices of unequal length (18 K tiles / 3 = 6, 18 / 9 = 2)
+    for ks in (1, 3, 4):   # no split; slices of equal (9 K tiles / 3) and unequal (9 / 4 -> 2, 2, 2, 3) length
         rc, got, out = run(n_img, ks)
         assert rc == 0 and got == ks, gemm.emu_last_error()
         close(out, ref + res.double())
