@@ -40,7 +40,7 @@ from oracle import torch_ref as R
 from text2human_amd import defaults, engine, ops, options, synthetic
 from text2human_amd.models import SampleFromParsingModel
 
-from parity_util import ACT_TOL, DEV, account, forced_run, odev, oracle_run, osds, seed_all
+from parity_util import ACT_TOL, DEV, account, forced_run, odev, oracle_run, osds, seed_all, vq_mismatch_accounting
 
 pytestmark = pytest.mark.gpu
 B, STEPS, SEED = 8, 256, 2021          # bench.py defaults (BASELINE.json configs[1])
@@ -66,6 +66,23 @@ def _full_parity(batch_size, peaked, tag, all_paths=True):
         tok_ref = R.segm_tokens(odev(batch['segm']), od['segm_encoder'], od['segm_quant_conv'],
                                 od['segm_quantizer']['embedding.weight']).view(batch_size, -1)
     report['segm_token_mismatches'] = int((model.segm_tokens.cpu() != tok_ref.cpu()).sum())
+    if report['segm_token_mismatches']:
+        # a codebook decision that differs must be a near-tie of THAT row (two exact-fp32 evaluations of 20 convolution
+        # layers in different summation orders; parity_util.vq_mismatch_accounting against the measured latent error);
+        # the oracle's tokens are then injected so that everything downstream is compared on identical inputs
+        # (tools/parity_more_seeds.py: 0 at seeds 2021 / 1 / 99 / 12345, one accounted near-tie at seed 7)
+        import torch.nn.functional as F
+        with torch.no_grad():
+            one_hot = F.one_hot(odev(batch['segm']).squeeze(1).long(), 24).permute(0, 3, 1, 2).float()
+            z_ref = F.conv2d(R.encoder(one_hot, od['segm_encoder']), od['segm_quant_conv']['weight'], od['segm_quant_conv']['bias'])
+            z_ref = z_ref.permute(0, 2, 3, 1).reshape(-1, z_ref.shape[1]).cpu()
+        x = ops.onehot_nhwc(model.segm.to(torch.float32).reshape(-1), 24, model.segm_cin_pad)
+        z_hip, _, _ = model.segm_encoder.encode(x, batch_size, 512, 256)
+        z_hip = ops.gemm(z_hip, model.P['segm.qc.w'], bias=model.P['segm.qc.b'])
+        acc_tok = vq_mismatch_accounting(z_hip, z_ref, sds['segm_quantizer']['embedding.weight'], model.segm_tokens, tok_ref)
+        report['segm_token_accounting'] = acc_tok
+        assert all(a['explained'] for a in acc_tok), acc_tok
+        model.segm_tokens = tok_ref.to(DEV).view_as(model.segm_tokens).contiguous()
     ref, trace, rng_state = oracle_run(model.segm_tokens, batch['texture_mask'], sd_dev, STEPS, SEED)
     ref_t = torch.stack(ref)
     assert (ref_t >= 0).sum().item() == batch_size * 512  # every token sampled exactly once
@@ -116,7 +133,7 @@ def _full_parity(batch_size, peaked, tag, all_paths=True):
         json.dump(report, f, indent=1)
     print(json.dumps(report))
 
-    assert report['segm_token_mismatches'] == 0, report['segm_token_mismatches']
+    assert report['segm_token_mismatches'] <= 4, report['segm_token_mismatches']   # (each one accounted above)
     for name, r in report['paths'].items():
         unexplained = [a for a in r['accounted'] if not a['explained']]
         assert not unexplained, f'{name}: {len(unexplained)} of {r["mismatches"]} mismatches are not float near-ties: {unexplained[:5]}'
@@ -129,6 +146,7 @@ def _full_parity(batch_size, peaked, tag, all_paths=True):
 @pytest.mark.parametrize('peaked', [False, True], ids=['default_weights', 'peaked_logits_x50'])
 def test_bench_config_parity(peaked):
     report = _full_parity(B, peaked, 'bench_config_' + ('peaked' if peaked else 'default'))
+    assert report['segm_token_mismatches'] == 0, report   # (the benchmarked batch, seed 2021: exact)
     if not peaked:
         # near-uniform logits: the race is decided by the noise, no near-tie is expected at all
         assert report['paths']['split_2xfp16']['mismatches'] == 0, report['paths']['split_2xfp16']
@@ -143,6 +161,7 @@ def test_parsing_batch_32_full_parity():
     chunks.  Teacher-forced 0 unexplained of 16384 decisions; free-running tokens == the eager-GPU oracle's;
     bottom indices 16384 / 16384; all 32 images within tolerance."""
     report = _full_parity(32, False, 'parsing_b32', all_paths=False)
+    assert report['segm_token_mismatches'] == 0, report
     assert report['paths']['split_2xfp16']['mismatches'] == 0, report['paths']['split_2xfp16']
     assert report['free_running']['split_vs_oracle_mismatches'] == 0, report['free_running']
 
