@@ -7,8 +7,8 @@ unexpected key or a shape mismatch raises RuntimeError.
 
 Repacks (device resident, done once at model construction; fp32, plus the two-fp16-plane "split
 row" copies of the sampler Linears and of the decoders' convolutions that the split-precision
-kernels multiply -- `pack_transformer`, `add_split_conv_weights`; the LayerNorm-folded copies only
-with T2H_FOLD_LN=1):
+kernels multiply -- `pack_transformer`, `add_split_conv_weights`; the x8 copies of the sampler Linears
+are packed by engine.SamplerNet.calibrate_x8 with each matrix's own power-of-two scale):
   * 3x3 conv  [Cout,Cin,3,3] -> [Cout, 9*Cin']  K order [tap(dy,dx)][cin],
     Cin' = Cin rounded up to a multiple of 32 (zero columns);
   * 1x1 conv  [Cout,Cin,1,1] -> [Cout, Cin];
