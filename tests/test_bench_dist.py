@@ -60,6 +60,21 @@ def test_bench_two_ranks_gloo():
 
 
 @pytest.mark.timeout(300)
+def test_bench_eight_ranks_gloo_is_the_drivers_node_shape():
+    """The driver's N = 8 launch (one rank per GPU of a node), on gloo with the stub model: eight shards of the global
+    batch, eight different checksums, max-over-ranks timing, per-rank core blocks, ONE line on rank 0 -- no 8-GPU node was
+    ever available, so this is the only execution of the eight-rank host logic."""
+    out = _run(8, ('--batch', '2'))
+    assert out['n_gpus'] == 8 and out['rccl_world'] == 8 and out['scaling'] == 'weak'
+    assert out['config']['global_batch'] == 16 and out['config']['parallelism'].startswith('batch shard x8')
+    assert len(out['per_rank_ms_per_step']) == 8 and out['ms_per_step'] >= max(out['per_rank_ms_per_step']) - 1e-6
+    assert abs(out['value'] - 16 * 1000.0 / out['ms_per_step']) < 1e-6 * out['value']
+    assert len(set(out['per_rank_image_checksum'])) == 8            # every rank its own shard
+    assert out['other_configs']['parsing_b32']['global_batch'] == 8 * 2 * 2
+    assert out['detail'] == 'gpurun_out/bench_detail_n8.json'
+
+
+@pytest.mark.timeout(300)
 def test_plain_python_bench_gpus_2_spawns_its_own_ranks():
     """`python bench.py --gpus 2 ...` WITHOUT a launcher -- the form the driver uses at N = 1 -- must
     produce a 2-rank line by itself (bench.spawn_ranks re-executes the command under torch.distributed.run)."""
